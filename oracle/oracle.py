@@ -1,0 +1,278 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY.
+
+CPU restatement (numpy / scipy + the serial C loops of oracle/loops.c) of the one hot path of
+snphbaum/scikit-gpuppy that this repository accelerates: ARD squared-exponential Gram matrix ->
+explicit inverse -> estimate_many -> Girard uncertainty propagation (Approx and Exact).
+
+It is the *checker* for the HIP path and the timed CPU baseline of bench.py (`cpu_baseline.kind =
+"port"`).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the
+product package (scikit-gpuppy_amd/) never does.
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks every function below against golden
+vectors produced by importing the genuine reference in the build container (tools/gen_golden.py ->
+tests/golden/*.npz) and against the known answers KAT1/KAT2 of SURVEY.md section 8c.
+
+The algorithm class is deliberately the reference's (so that timing it is not a straw man):
+GEMM-expansion Gram with full N1xN2 temporaries, LU `scipy.linalg.inv`, GEMM-based estimate_many
+including the MxM products, explicit-Kinv serial double sums.  Citations are file:line into the
+reference tree.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+from scipy.linalg import cholesky, inv, solve_triangular
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LOOPS = None
+
+
+def build_loops(force=False):
+    """Compile oracle/loops.c with gcc (no fast-math) into oracle/liboracle_loops.so."""
+    so = os.path.join(_HERE, "liboracle_loops.so")
+    src = os.path.join(_HERE, "loops.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", so, src, "-lm"])
+    return so
+
+
+def _loops():
+    global _LOOPS
+    if _LOOPS is None:
+        lib = ctypes.CDLL(build_loops())
+        dp = ctypes.POINTER(ctypes.c_double)
+        L = ctypes.c_long
+        lib.orc_quad_form.restype = ctypes.c_double
+        lib.orc_quad_form.argtypes = [dp, dp, L]
+        lib.orc_var2.restype = ctypes.c_double
+        lib.orc_var2.argtypes = [dp, dp, dp, dp, L, L]
+        lib.orc_var3.restype = ctypes.c_double
+        lib.orc_var3.argtypes = [dp, dp, dp, L]
+        lib.orc_dvh2.restype = ctypes.c_double
+        lib.orc_dvh2.argtypes = [dp, dp, dp, L, L, L]
+        lib.orc_exact_sum.restype = ctypes.c_double
+        lib.orc_exact_sum.argtypes = [dp, dp, dp, dp, dp, dp, ctypes.c_double, L, L]
+        _LOOPS = lib
+    return _LOOPS
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------------
+# L1: covariance operator  (reference: skgpuppy/Covariance.py, class GaussianCovariance)
+# --------------------------------------------------------------------------------------------
+
+def unpack_theta(theta):
+    """theta = (log v, log vt, log w_1..w_d)   (Covariance.py:442-445, :467-470)."""
+    with np.errstate(divide="ignore"):
+        theta = np.asarray(theta, dtype=float)
+        return np.exp(theta[0]), np.exp(theta[1]), np.exp(theta[2:])
+
+
+def scalar_cov(xi, xj, theta):
+    """k(xi,xj) = v exp(-1/2 sum_k w_k (xi_k-xj_k)^2) + vt iff xi == xj elementwise
+    (Covariance.py:440-451, the "slightly dirty hack" at :450-451)."""
+    v, vt, w = unpack_theta(theta)
+    xi = np.asarray(xi)
+    xj = np.asarray(xj)
+    diff = xi - xj
+    return v * np.exp(-0.5 * np.dot(diff, w * diff)) + (vt if (xi == xj).all() else 0.0)
+
+
+def gram_ij(xi, xj, theta):
+    """N1 x N2 cross-covariance WITHOUT the noise term, via the ||a||^2+||b||^2-2ab expansion on
+    sqrt(w)-scaled inputs (Covariance.py:466-483)."""
+    v, _vt, w = unpack_theta(theta)
+    sw = np.sqrt(w)
+    a = np.array(xi, dtype=float) * sw
+    b = np.array(xj, dtype=float) * sw
+    n1, n2 = a.shape[0], b.shape[0]
+    D = -2.0 * np.dot(a, b.T)
+    D += np.tile((b * b).sum(1)[None, :], (n1, 1))
+    D += np.tile((a * a).sum(1)[:, None], (1, n2))
+    return v * np.exp(-0.5 * D)
+
+
+def gram(x, theta):
+    """K = gram_ij(x,x) + vt I  (Covariance.py:461-464)."""
+    _v, vt, _w = unpack_theta(theta)
+    return gram_ij(x, x, theta) + vt * np.eye(len(x))
+
+
+def inv_cov_matrix(x, theta, cov_matrix=None):
+    """LU inverse of K; jittered-Cholesky fallback on ValueError (Covariance.py:167-187)."""
+    if cov_matrix is not None:
+        return inv(cov_matrix)
+    K = gram(x, theta)
+    try:
+        return inv(K)
+    except ValueError:
+        m = len(K)
+        L = cholesky(K + np.eye(m) * 1e-5, lower=True)
+        Linv = solve_triangular(L, np.eye(m), lower=True)
+        return np.dot(Linv.T, Linv)
+
+
+def hessian(u, xi, theta):
+    """H[a,b] = (w_a d_a w_b d_b - w_a [a==b]) v exp(-1/2 d^T W d), d = xi - u  (Covariance.py:660-674)."""
+    v, _vt, w = unpack_theta(theta)
+    d = np.asarray(xi, dtype=float) - np.asarray(u, dtype=float)
+    e = v * np.exp(-0.5 * np.dot(d, w * d))
+    wd = w * d
+    return (np.outer(wd, wd) - np.diag(w)) * e
+
+
+def jacobian(u, xi, theta):
+    """J = -(xi-u) * w * c as a (d,1) column  (Covariance.py:676-689)."""
+    v, _vt, w = unpack_theta(theta)
+    d = np.asarray(xi, dtype=float) - np.asarray(u, dtype=float)
+    e = v * np.exp(-0.5 * np.dot(d, w * d))
+    return np.atleast_2d(-d * w * e).T
+
+
+# --------------------------------------------------------------------------------------------
+# L2: GP object  (reference: skgpuppy/GaussianProcess.py)
+# --------------------------------------------------------------------------------------------
+
+class OracleGP(object):
+    """fit = centre targets + explicit Kinv  (GaussianProcess.py:19-41)."""
+
+    def __init__(self, x, t, theta):
+        self.x = x
+        self.n, self.d = np.shape(x)
+        self.meant = np.mean(t)
+        self.t = np.asarray(t, dtype=float) - self.meant
+        self.theta_min = np.asarray(theta, dtype=float)
+        self.Kinv = inv_cov_matrix(self.x, self.theta_min)
+
+    def beta(self):
+        """beta = Kinv t, recomputed on every call  (GaussianProcess.py:114-119)."""
+        return np.dot(self.Kinv, self.t)
+
+    def estimate_many(self, x_stars):
+        """mean = kv (Kinv t) + meant; var = diag(k - kv Kinv kv^T), k = Gram(x*)+vt I
+        (GaussianProcess.py:68-80) -- including the M x M products the reference forms."""
+        xs = np.array(x_stars)
+        k = gram(xs, self.theta_min)
+        kv = gram_ij(xs, self.x, self.theta_min)
+        mean = np.dot(kv, np.dot(self.Kinv, self.t))
+        var = k - np.dot(kv, np.dot(self.Kinv, kv.T))
+        return mean + self.meant, np.diag(var)
+
+    def estimate(self, x_star):
+        """single-point twin  (GaussianProcess.py:94-111)."""
+        xs = np.array(x_star)
+        k = scalar_cov(xs, xs, self.theta_min)
+        kv = gram_ij(np.atleast_2d(xs), self.x, self.theta_min)
+        mean = np.dot(kv, np.dot(self.Kinv, self.t))
+        var = k - np.dot(kv, np.dot(self.Kinv, kv.T))
+        return mean[0] + self.meant, var[0, 0]
+
+    def logdet(self):
+        """Covariance.py:189-195."""
+        return np.linalg.slogdet(gram(self.x, self.theta_min))[1]
+
+
+# --------------------------------------------------------------------------------------------
+# L3: uncertainty propagation  (reference: skgpuppy/UncertaintyPropagation.py, ...2.pyx)
+# --------------------------------------------------------------------------------------------
+
+def cjh(gp, u):
+    """C_ux[N], J_ux[N,d,1], H_ux[N,d,d] by N point-wise evaluations (UncertaintyPropagation.py:504-510),
+    C through the scalar kernel so the +vt-on-equality quirk applies."""
+    x = np.asarray(gp.x)
+    C = np.array([scalar_cov(u, x[i], gp.theta_min) for i in range(gp.n)])
+    J = np.array([jacobian(u, x[i], gp.theta_min) for i in range(gp.n)])
+    H = np.array([hessian(u, x[i], gp.theta_min) for i in range(gp.n)])
+    return C, J, H
+
+
+def approx_parts(gp, u, Sigma, cache=None):
+    """(mean_without_meant, sigma2, variance_rest) of UncertaintyPropagationApprox
+    (UncertaintyPropagation.py:397-408, :412-433, :435-481)."""
+    C, J, H = cache if cache is not None else cjh(gp, u)
+    Sigma = np.asarray(Sigma, dtype=float)
+    beta = gp.beta()
+    Kinv = _c(gp.Kinv)
+    n, d = gp.n, gp.d
+    tr = np.array([np.dot(np.ravel(H[i].T), np.ravel(Sigma)) for i in range(n)])  # tracedot, Covariance.py:101-109
+    mean = float(np.dot(beta, C)) + 0.5 * float(np.dot(beta, tr))
+    lib = _loops()
+    Cc, Jc, trc, bc = _c(C), _c(J.reshape(n, d)), _c(tr), _c(beta)
+    S = _c(np.diag(Sigma))
+    v, vt, _w = unpack_theta(gp.theta_min)
+    sigma2 = (v + vt) - lib.orc_quad_form(_p(Kinv), _p(Cc), n)           # C(u,u) = v + vt (a3 quirk)
+    var2 = lib.orc_var2(_p(Kinv), _p(bc), _p(Jc), _p(S), n, d)
+    var3 = lib.orc_var3(_p(Kinv), _p(Cc), _p(trc), n)
+    return mean, sigma2, var2 + var3
+
+
+def approx_propagate(gp, u, Sigma, cache=None):
+    """UncertaintyPropagationApprox.propagate_GA  (UncertaintyPropagation.py:490-523)."""
+    mean, sigma2, rest = approx_parts(gp, u, Sigma, cache)
+    return mean + gp.meant, sigma2 + rest
+
+
+def approx_factor(gp, u, Sigma, v_out, cache=None):
+    """_getFactor = (v_out - sigma2) / rest  (UncertaintyPropagation.py:526-560)."""
+    _m, sigma2, rest = approx_parts(gp, u, Sigma, cache)
+    return (v_out - sigma2) / rest
+
+
+def approx_dvh(gp, u, h, cache=None):
+    """_get_variance_dv_h  (UncertaintyPropagation.py:564-630 / .pyx:340-380)."""
+    C, J, H = cache if cache is not None else cjh(gp, u)
+    beta = gp.beta()
+    Kinv = _c(gp.Kinv)
+    n, d = gp.n, gp.d
+    lib = _loops()
+    hh = _c(H[:, h, h])
+    v2 = lib.orc_dvh2(_p(Kinv), _p(_c(beta)), _p(_c(J.reshape(n, d))), n, d, h)
+    v3 = lib.orc_var3(_p(Kinv), _p(_c(C)), _p(hh), n)
+    return v2 + v3
+
+
+def exact_mean(gp, u, Sigma, C=None):
+    """UncertaintyPropagationExact.propagate_mean  (UncertaintyPropagation.py:247-290):
+    Delta^-1 = W^-1 - diag(w_k/(1+w_k S_kk)), nc1 = det(I + Winv*Sigma [elementwise])^-1/2."""
+    x = np.asarray(gp.x, dtype=float)
+    u = np.asarray(u, dtype=float)
+    Sigma = np.asarray(Sigma, dtype=float)
+    _v, _vt, w = unpack_theta(gp.theta_min)
+    if C is None:
+        C = np.array([scalar_cov(u, x[i], gp.theta_min) for i in range(gp.n)])
+    Winv = np.diag(w)
+    Dinv = Winv - np.diag(w / (1.0 + w * np.diag(Sigma)))
+    nc1 = 1.0 / np.sqrt(np.linalg.det(np.eye(gp.d) + Winv * Sigma))
+    beta = gp.beta()
+    s = 0.0
+    for i in range(gp.n):
+        a = u - x[i]
+        s += beta[i] * C[i] * nc1 * np.exp(0.5 * np.dot(a, np.dot(Dinv, a)))
+    return s
+
+
+def exact_propagate(gp, u, Sigma):
+    """UncertaintyPropagationExact.propagate_GA  (UncertaintyPropagation.py:292-303, :323-379; K1 with the
+    explicit d^2 loop of UncertaintyPropagation2.pyx:173-179)."""
+    x = _c(gp.x)
+    u = _c(u)
+    Sigma = np.asarray(Sigma, dtype=float)
+    v, vt, w = unpack_theta(gp.theta_min)
+    Winv = np.diag(w)
+    W = np.diag(1.0 / w)
+    Linv = _c(2.0 * Winv - inv(0.5 * W + Sigma))
+    nc2 = 1.0 / np.sqrt(np.linalg.det(2.0 * Winv * Sigma + np.eye(gp.d)))
+    C = _c(np.array([scalar_cov(u, x[i], gp.theta_min) for i in range(gp.n)]))
+    mu = exact_mean(gp, u, Sigma, C)
+    beta = _c(gp.beta())
+    Kinv = _c(gp.Kinv)
+    s = _loops().orc_exact_sum(_p(Kinv), _p(beta), _p(C), _p(x), _p(u), _p(Linv), float(nc2), gp.n, gp.d)
+    return mu + gp.meant, (v + vt) - s - mu ** 2

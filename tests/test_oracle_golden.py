@@ -1,0 +1,131 @@
+"""Pin the oracle (CPU restatement) against golden vectors generated from the genuine reference
+(tools/gen_golden.py) and the known answers KAT1 / KAT2 of SURVEY.md section 8c.  CPU only."""
+import numpy as np
+import pytest
+
+from conftest import GP_CASES, load_golden
+from oracle import oracle as orc
+
+GRAM_CASES = ["grid_int", "n257_d5", "n64_d16", "rect_33x257_d5", "n257_d5_vt0", "n130_d1"]
+
+
+@pytest.mark.parametrize("name", GRAM_CASES)
+def test_gram_matches_reference(name):
+    g = load_golden("gram")
+    xi, xj, th = g[name + "__xi"], g[name + "__xj"], g[name + "__theta"]
+    with np.errstate(divide="ignore"):
+        K = orc.gram_ij(xi, xj, th)
+        np.testing.assert_allclose(K, g[name + "__K_ij"], rtol=1e-14, atol=0)
+        if name + "__K" in g:
+            np.testing.assert_allclose(orc.gram(xi, th), g[name + "__K"], rtol=1e-14, atol=0)
+
+
+def test_scalar_cov_quirk():
+    th = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
+    a = np.array([5.0, 5.0])
+    assert orc.scalar_cov(a, a.copy(), th) == pytest.approx(2.01, abs=1e-15)   # +vt on equality
+    assert orc.scalar_cov(a, a + 1e-9, th) < 2.0 + 1e-12                      # no vt otherwise
+
+
+@pytest.fixture(scope="module", params=GP_CASES)
+def case(request):
+    g = load_golden(request.param)
+    gp = orc.OracleGP(g["x"], g["t_raw"], g["theta"])
+    return request.param, g, gp
+
+
+def test_fit(case):
+    name, g, gp = case
+    assert gp.meant == pytest.approx(float(g["meant"]), abs=1e-15)
+    np.testing.assert_allclose(gp.t, g["t_centered"], rtol=0, atol=1e-15)
+    scale = 1e-7 if name == "metis" else 1e-9      # LU inverse at cond 1.6e7 / <=1e6
+    if "Kinv" in g:
+        np.testing.assert_allclose(gp.Kinv, g["Kinv"], rtol=scale, atol=scale * np.abs(g["Kinv"]).max())
+    np.testing.assert_allclose(gp.beta(), g["beta"], rtol=1e-7, atol=1e-7 * np.abs(g["beta"]).max())
+    assert gp.logdet() == pytest.approx(float(g["logdet"]), rel=1e-10)
+
+
+def test_estimate_many(case):
+    name, g, gp = case
+    v = np.exp(g["theta"][0])
+    mean, var = gp.estimate_many(g["xs"])
+    np.testing.assert_allclose(mean, g["pred_mean"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(var, g["pred_var"], rtol=1e-9, atol=1e-10 * v)
+    m0, v0 = gp.estimate(g["xs"][0])
+    assert m0 == pytest.approx(g["est0"][0], abs=1e-10)
+    assert v0 == pytest.approx(g["est0"][1], abs=1e-10 * v)
+
+
+def test_propagation(case):
+    name, g, gp = case
+    v = np.exp(g["theta"][0])
+    tol = 1e-9 * v
+    for iu in range(int(g["nu"])):
+        u = g["u%d" % iu]
+        C, J, H = orc.cjh(gp, u)
+        np.testing.assert_allclose(C, g["C_ux_u%d" % iu], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(J, g["J_ux_u%d" % iu], rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(H, g["H_ux_u%d" % iu], rtol=1e-13, atol=1e-300)
+        dv = np.array([orc.approx_dvh(gp, u, h, (C, J, H)) for h in range(gp.d)])
+        np.testing.assert_allclose(dv, g["dvh_u%d" % iu], rtol=1e-7, atol=tol * 10)
+        for iS in range(int(g["nS"])):
+            S = g["Sigma%d" % iS]
+            ma, va = orc.approx_propagate(gp, u, S, (C, J, H))
+            ref = g["approx_u%d_S%d" % (iu, iS)]
+            assert ma == pytest.approx(ref[0], abs=1e-10)
+            assert va == pytest.approx(ref[1], abs=tol)
+            f = orc.approx_factor(gp, u, S, float(g["v_out"]), (C, J, H))
+            assert f == pytest.approx(float(g["factor_u%d_S%d" % (iu, iS)]), rel=1e-6)
+            key = "exact_u%d_S%d" % (iu, iS)
+            if key in g:
+                me, ve = orc.exact_propagate(gp, u, S)
+                assert me == pytest.approx(g[key][0], abs=1e-10)
+                assert ve == pytest.approx(g[key][1], abs=tol)
+                mo = orc.exact_mean(gp, u, S)
+                assert mo == pytest.approx(float(g["exact_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-10)
+
+
+def test_kat1_known_answers():
+    """SURVEY.md 8c KAT1 literals (obtained from the reference during the survey)."""
+    g = load_golden("kat1_grid")
+    gp = orc.OracleGP(g["x"], g["t_raw"], g["theta"])
+    assert gp.meant == pytest.approx(0.19262764562720766, abs=1e-15)
+    mean, var = gp.estimate_many([[.5, .5], [4.5, 5], [9, 9], [2.25, 7.75]])
+    np.testing.assert_allclose(mean, [0.3141169314449207, 0.28604463521448886, -0.7801159965052474,
+                                      0.1491755086576004], atol=1e-11)
+    np.testing.assert_allclose(var, [0.01187314685897833, 0.0108845405331639, 0.01498150754166194,
+                                     0.01115813990257708], atol=1e-11)
+    assert gp.Kinv[0, 0] == pytest.approx(50.18492458367548, rel=1e-10)
+    assert gp.Kinv[0, 1] == pytest.approx(-25.607400325654574, rel=1e-10)
+    assert gp.Kinv[55, 55] == pytest.approx(91.17198500797619, rel=1e-10)
+    S = np.diag([0.01, 0.01])
+    u = np.array([5.0, 5.0])                                  # equals a training row: quirk active
+    assert orc.approx_propagate(gp, u, S) == pytest.approx((0.18983893618073702, 0.0018348329974112298), abs=1e-10)
+    assert orc.exact_propagate(gp, u, S) == pytest.approx((0.18981740098493302, 0.0018392233503982257), abs=1e-10)
+    dv = [orc.approx_dvh(gp, u, h) for h in range(2)]
+    assert dv == pytest.approx([0.09267874425295342, 0.09080455550079503], abs=1e-9)
+    assert orc.approx_factor(gp, u, np.diag([1.0, 2.0]), 0.02) == pytest.approx(0.07291609751209138, rel=1e-7)
+    u = np.array([5.25, 4.75])
+    assert orc.approx_propagate(gp, u, S) == pytest.approx((0.13524300017798102, 0.01271034188082463), abs=1e-10)
+    assert orc.exact_propagate(gp, u, S) == pytest.approx((0.13524304792303363, 0.012706742317055097), abs=1e-10)
+
+
+def test_kat2_metis_known_answers():
+    """SURVEY.md 8c KAT2 (METIS data held by the reference's tests, fixed theta)."""
+    g = load_golden("metis")
+    gp = orc.OracleGP(g["x"], g["t_raw"], g["theta"])
+    u = np.array([15.05, 5.0, 0.025])
+    S = np.diag([4.0, 1.0, 2.5e-5])
+    m, v = gp.estimate(u)
+    assert m == pytest.approx(0.3037105446529179, abs=1e-8)
+    assert v == pytest.approx(2.1113158520658093e-05, abs=1e-8)
+    ma, va = orc.approx_propagate(gp, u, S)
+    assert (ma, va) == pytest.approx((0.30309549405529035, 0.0016887385637408547), abs=1e-8)
+    me, ve = orc.exact_propagate(gp, u, S)
+    assert (me, ve) == pytest.approx((0.3030869237925962, 0.0017031624981441612), abs=1e-8)
+    # the reference's own METIS assertions (tests.py:1381-1409): code uncertainty < 6e-4 and
+    # sqrt(var - code_u) of both propagators inside the Monte-Carlo confidence interval
+    code_u = v - np.exp(g["theta"][1])
+    assert np.sqrt(code_u) < 0.0006
+    for var in (va, ve):
+        assert 0.0410788036621 < np.sqrt(var - code_u) < 0.0422334526251

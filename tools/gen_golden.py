@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by importing the genuine reference.
+
+Runs ONLY in the build container, where the reference tree is mounted at
+/root/reference (read-only).  Nothing of the reference travels: this script
+writes explicit input AND output arrays (never RNG seeds) to tests/golden/*.npz.
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tools/gen_golden.py
+
+Shims (harness side, the reference tree is never edited): skgpuppy/Utilities.py:10
+imports scipy.integrate.romberg (removed in SciPy 1.15) and MLE.py / TaylorPropagation.py
+import scipy.misc.derivative; dummies are installed before the import so that
+skgpuppy.UncertaintyPropagation (pure-Python backend: weaving=False, cython=False)
+can be imported.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("GPX_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def _install_shims():
+    import scipy.integrate
+    if not hasattr(scipy.integrate, "romberg"):
+        def _romberg(*a, **k):
+            raise NotImplementedError("romberg removed from SciPy")
+        scipy.integrate.romberg = _romberg
+    if not hasattr(np, "Inf"):
+        np.Inf = np.inf
+    try:
+        import scipy.misc as _m
+    except Exception:  # pragma: no cover
+        _m = types.ModuleType("scipy.misc")
+        sys.modules["scipy.misc"] = _m
+    if not hasattr(_m, "derivative"):
+        def _derivative(*a, **k):
+            raise NotImplementedError
+        _m.derivative = _derivative
+
+
+def _import_reference():
+    _install_shims()
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from skgpuppy.Covariance import GaussianCovariance
+    from skgpuppy.GaussianProcess import GaussianProcess
+    import skgpuppy.UncertaintyPropagation as UP
+    assert not UP.weaving and not UP.cython, "expected the pure-Python backend"
+    return GaussianCovariance, GaussianProcess, UP
+
+
+def synth(N, d, M, seed_offset=0):
+    """BASELINE.md §3 recipe."""
+    rng = np.random.RandomState(20240 + N + d + seed_offset)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    return x, t, xs, theta
+
+
+def gram_cases(GC):
+    cov = GC()
+    out = {}
+    rng = np.random.RandomState(7)
+    # (name, xi, xj, theta)
+    grid = np.array([[a, b] for a in range(10) for b in range(10)])  # int dtype, README.rst:100
+    th2 = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
+    cases = [("grid_int", grid, grid, th2)]
+    x257 = rng.uniform(-3, 3, (257, 5))
+    th5 = np.array([0.3, -2.0, -1.0, 0.2, -0.5, 0.7, -2.2])
+    cases.append(("n257_d5", x257, x257, th5))
+    x64 = rng.randn(64, 16)
+    th16 = np.concatenate([[0.1, -3.0], rng.uniform(-3, -1, 16)])
+    cases.append(("n64_d16", x64, x64, th16))
+    x33 = rng.uniform(-3, 3, (33, 5))
+    cases.append(("rect_33x257_d5", x33, x257, th5))
+    th_novt = th5.copy()
+    th_novt[1] = -np.inf  # vt = 0 appears in the reference's tests
+    cases.append(("n257_d5_vt0", x257, x257, th_novt))
+    x1 = rng.uniform(0, 1, (130, 1))
+    cases.append(("n130_d1", x1, x1, np.array([0.0, -4.0, 2.0])))
+    for name, xi, xj, th in cases:
+        out["%s__xi" % name] = xi
+        out["%s__xj" % name] = xj
+        out["%s__theta" % name] = th
+        with np.errstate(divide="ignore"):
+            out["%s__K_ij" % name] = cov.cov_matrix_ij(xi, xj, th)
+            if xi is xj:
+                out["%s__K" % name] = cov.cov_matrix(xi, th)
+    return out
+
+
+def gp_case(GC, GP, UP, x, t, theta, xs, us, Sigmas, v_out=0.02, keep_kinv=True,
+            with_exact=True):
+    """Fit + predict + propagate one configuration; returns a flat dict of arrays."""
+    cov = GC()
+    gp = GP(x, np.array(t, dtype=float), cov, np.array(theta, dtype=float))
+    o = {"x": x, "t_raw": np.asarray(t), "theta": np.asarray(theta, dtype=float), "xs": xs}
+    o["meant"] = np.float64(gp.meant)
+    o["t_centered"] = gp.t
+    if keep_kinv:
+        o["Kinv"] = gp.Kinv
+    o["beta"] = gp._get_beta()
+    sign, logdet = np.linalg.slogdet(cov.cov_matrix(x, gp.theta_min))
+    o["logdet"] = np.float64(logdet)
+    mean, var = gp.estimate_many(xs)
+    o["pred_mean"] = mean
+    o["pred_var"] = var
+    m1, v1 = gp.estimate(xs[0])
+    o["est0"] = np.array([m1, v1])
+    o["nu"] = np.int64(len(us))
+    o["nS"] = np.int64(len(Sigmas))
+    x = np.asarray(x)
+    for iu, u in enumerate(us):
+        u = np.array(u, dtype=float)
+        o["u%d" % iu] = u
+        for iS, S in enumerate(Sigmas):
+            S = np.array(S, dtype=float)
+            o["Sigma%d" % iS] = S
+            upa = UP.UncertaintyPropagationApprox(gp)
+            ma, va = upa.propagate_GA(u, S)
+            o["approx_u%d_S%d" % (iu, iS)] = np.array([ma, va])
+            o["approx_mean_only_u%d_S%d" % (iu, iS)] = np.float64(upa.propagate_mean(u, S))
+            if iS == 0:
+                o["C_ux_u%d" % iu] = upa.C_ux
+                o["J_ux_u%d" % iu] = upa.J_ux
+                o["H_ux_u%d" % iu] = upa.H_ux
+                o["dvh_u%d" % iu] = np.array(
+                    [upa._get_variance_dv_h(u, h) for h in range(x.shape[1])])
+            o["factor_u%d_S%d" % (iu, iS)] = np.float64(upa._getFactor(u, S, v_out))
+            if with_exact:
+                upe = UP.UncertaintyPropagationExact(gp)
+                me, ve = upe.propagate_GA(u, S)
+                o["exact_u%d_S%d" % (iu, iS)] = np.array([me, ve])
+                o["exact_mean_only_u%d_S%d" % (iu, iS)] = np.float64(upe.propagate_mean(u, S))
+    o["v_out"] = np.float64(v_out)
+    return o
+
+
+def main():
+    GC, GP, UP = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    np.savez_compressed(os.path.join(OUT, "gram.npz"), **gram_cases(GC))
+    print("gram.npz")
+
+    # KAT1: float README grid, deterministic target.
+    a, b = np.meshgrid(np.arange(10.0), np.arange(10.0), indexing="ij")
+    xg = np.stack([a.ravel(), b.ravel()], 1)
+    tg = np.sin(0.3 * (xg[:, 0] + xg[:, 1])) + 0.05 * np.cos(1.7 * xg[:, 0] - 0.4 * xg[:, 1])
+    thg = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
+    xs_g = np.array([[x1 / 2.0, x2 / 2.0] for x1 in range(20) for x2 in range(20)])  # README.rst:120
+    xs_g[:4] = [[.5, .5], [4.5, 5], [9, 9], [2.25, 7.75]]
+    full = np.array([[0.01, 0.004], [0.004, 0.02]])
+    c = gp_case(GC, GP, UP, xg, tg, thg, xs_g,
+                us=[[5.0, 5.0], [5.25, 4.75]],
+                Sigmas=[np.diag([0.01, 0.01]), np.diag([1.0, 2.0]), full])
+    np.savez_compressed(os.path.join(OUT, "kat1_grid.npz"), **c)
+    print("kat1_grid.npz")
+
+    # integer-dtype grid exactly as the README builds it (x stored as given).
+    xi = np.array([[x1, x2] for x1 in range(10) for x2 in range(10)])
+    c = gp_case(GC, GP, UP, xi, tg, thg, xs_g[:7], us=[[5.0, 5.0]],
+                Sigmas=[np.diag([0.01, 0.01])], with_exact=False)
+    np.savez_compressed(os.path.join(OUT, "grid_int.npz"), **c)
+    print("grid_int.npz")
+
+    # generic d=3 ragged N (not a multiple of any tile), u generic and u == training row.
+    x, t, xs, th = synth(203, 3, 37)
+    th = np.array([0.4, -3.5, -1.2, -0.7, -1.9])
+    Sd = np.diag([0.02, 0.05, 0.01])
+    Sf = np.array([[0.02, 0.005, -0.002], [0.005, 0.05, 0.003], [-0.002, 0.003, 0.01]])
+    c = gp_case(GC, GP, UP, x, t, th, xs, us=[[4.0, 5.5, 6.0], x[17].copy()], Sigmas=[Sd, Sf])
+    np.savez_compressed(os.path.join(OUT, "n203_d3.npz"), **c)
+    print("n203_d3.npz")
+
+    # d=8 recipe at N=256 (a tile multiple), M=400; Kinv kept.
+    x, t, xs, th = synth(256, 8, 400)
+    c = gp_case(GC, GP, UP, x, t, th, xs, us=[[5.0] * 8], Sigmas=[0.01 * np.eye(8)])
+    np.savez_compressed(os.path.join(OUT, "n256_d8.npz"), **c)
+    print("n256_d8.npz")
+
+    # medium: N=1000 d=4 recipe, M=64 — crosses several 128-blocks; Kinv dropped (size).
+    x, t, xs, th = synth(1000, 4, 64)
+    c = gp_case(GC, GP, UP, x, t, th, xs, us=[[5.0] * 4], Sigmas=[0.01 * np.eye(4)],
+                keep_kinv=False)
+    np.savez_compressed(os.path.join(OUT, "n1000_d4.npz"), **c)
+    print("n1000_d4.npz")
+
+    # d=16, N=300.
+    x, t, xs, th = synth(300, 16, 50)
+    c = gp_case(GC, GP, UP, x, t, th, xs, us=[[5.0] * 16], Sigmas=[0.01 * np.eye(16)],
+                keep_kinv=False)
+    np.savez_compressed(os.path.join(OUT, "n300_d16.npz"), **c)
+    print("n300_d16.npz")
+
+    # KAT2 / G6: METIS data held by the reference's own tests (tests/metis_data.py), fixed theta.
+    from skgpuppy.tests.metis_data import x as xm, t as tm
+    thm = np.array([-0.84329102, -10.77816567, -7.68527421, -5.47537322, 6.78674556])
+    um = np.array([15.05, 5.0, 0.025])
+    Sm = np.diag([2.0 ** 2, 1.0 ** 2, 0.005 ** 2])
+    xs_m = np.vstack([um, xm[:20] * 1.001])
+    c = gp_case(GC, GP, UP, np.array(xm, dtype=float), np.array(tm, dtype=float), thm, xs_m,
+                us=[um], Sigmas=[Sm], keep_kinv=False, v_out=0.002)
+    np.savez_compressed(os.path.join(OUT, "metis.npz"), **c)
+    print("metis.npz")
+
+
+if __name__ == "__main__":
+    main()
