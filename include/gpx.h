@@ -1,0 +1,142 @@
+/*
+ * gpx.h -- C-ABI of libgpx: MI355X (gfx950) native GP-regression + uncertainty-propagation core.
+ *
+ * This is the drop-in boundary for the ONE hot path of snphbaum/scikit-gpuppy
+ * (Gram build -> N x N factorisation/solves -> estimate_many -> propagate_GA, fp64,
+ * GaussianCovariance).  The reference has no FFI of its own: its "plugin boundary" is the Python
+ * operator interface `Covariance` (skgpuppy/Covariance.py:111-359) and the class substitution at
+ * import of the propagation classes (skgpuppy/UncertaintyPropagation.py:10-21,244).  A ctypes
+ * binding of exactly these entry points is what replaces the numpy/scipy/Cython calls; the
+ * reference-side stub a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - all arrays fp64, C-contiguous row-major, caller-owned.  Every `const double*` input and every
+ *     output pointer may be a HOST pointer (NumPy buffer) or a DEVICE pointer (HBM-resident buffer,
+ *     e.g. a torch tensor's data_ptr): copies use hipMemcpyDefault, device pointers are used in place.
+ *   - theta = (log v, log vt, log w_1..w_d) exactly as the reference's theta_min, always a host pointer.
+ *   - return 0 = ok; >0 = LAPACK-style info (leading minor not positive definite, also after the
+ *     +1e-5*I retry that mirrors skgpuppy/Covariance.py:180-185); <0 = bad argument / HIP error
+ *     (text via gpx_last_error()).  No exception crosses the ABI.
+ *   - a handle is single-owner (one HIP stream, not re-entrant); distinct handles may be used from
+ *     distinct threads.  There is NO CPU fallback: without a usable gfx950 device every compute
+ *     entry point returns GPX_ERR_NO_DEVICE.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_ABI_VERSION 1
+#define GPX_MAX_D 64          /* largest supported input dimension d */
+#define GPX_TILE 128          /* block size of the factorisation (rows are padded to it on device) */
+
+#define GPX_ERR_BAD_ARG   (-1)
+#define GPX_ERR_HIP       (-2)
+#define GPX_ERR_NO_DEVICE (-3)
+#define GPX_ERR_STATE     (-4)
+
+typedef struct gpx_handle gpx_handle;
+
+/* ---- library ---- */
+int         gpx_abi_version(void);
+const char *gpx_last_error(void);                 /* thread-local text of the last failure */
+int         gpx_device_count(void);               /* number of visible HIP devices (0 if none) */
+int         gpx_set_device(int device);           /* device used by subsequently created handles */
+
+/* ---- a1/a2: GaussianCovariance.cov_matrix_ij / cov_matrix  (skgpuppy/Covariance.py:461-483) ----
+ * K_out[n1,n2] = v exp(-1/2 sum_k w_k (xi_k - xj_k)^2); add_diag (= vt for cov_matrix, 0 for
+ * cov_matrix_ij) is added where row == col.  xj may alias xi. */
+int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t n2, int d,
+             const double *theta, double add_diag, double *K_out);
+
+/* ---- a4/a5: GaussianProcess.__init__ with theta given + Covariance.inv_cov_matrix
+ * (skgpuppy/GaussianProcess.py:19-41, skgpuppy/Covariance.py:167-187) ----
+ * Builds K = Gram(x,x) + vt I in HBM, factors it (blocked fp64 Cholesky instead of the reference's
+ * LU inverse), solves for alpha = K^-1 t.  t_centered = t - mean(t) (the caller keeps `meant`).
+ * On a non-positive pivot the factorisation is repeated once on K + 1e-5 I (reference fallback).
+ * stream: a hipStream_t to run on (0 / NULL = the library creates its own). */
+int gpx_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta,
+            void *stream, gpx_handle **out);
+void gpx_free(gpx_handle *h);
+
+int gpx_n(const gpx_handle *h, int64_t *n, int *d);
+int gpx_jitter_used(const gpx_handle *h, double *jitter);   /* 0.0 or 1e-5 */
+int gpx_logdet(gpx_handle *h, double *logdet);               /* log det K  (Covariance.py:189-195) */
+
+/* ---- a6/a7: GaussianProcess.estimate_many / estimate  (skgpuppy/GaussianProcess.py:68-111) ----
+ * mean_out[m] = kv alpha   (the caller adds `meant`),  var_out[m] = v + vt - kv K^-1 kv^T.
+ * Never forms the M x M matrices of the reference. */
+int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *mean_out, double *var_out);
+
+/* ---- a8: accessors ---- */
+int gpx_alpha(gpx_handle *h, double *beta_out);     /* beta = K^-1 t  [n]   (GaussianProcess.py:114-119) */
+int gpx_kinv(gpx_handle *h, double *Kinv_out);      /* K^-1 [n,n], materialised lazily on device
+                                                       (GaussianProcess.Kinv attribute, :41, :152-164) */
+int gpx_chol(gpx_handle *h, double *L_out);         /* lower Cholesky factor [n,n] (zeros above the diagonal) */
+
+/* ---- a9-a11: C_ux / J_ux / H_ux for a propagation input u
+ * (skgpuppy/UncertaintyPropagation.py:504-510; Covariance.py:440-451, :660-689) ----
+ * C[n] (with the +vt-on-exact-equality quirk), J[n,d] (= J_ux[:, :, 0]), H[n,d,d].  Any of the three
+ * may be NULL. */
+int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, double *H);
+
+/* ---- a12: UncertaintyPropagationApprox.propagate_GA / propagate_mean / _getFactor parts
+ * (skgpuppy/UncertaintyPropagation.py:386-560, UncertaintyPropagation2.pyx:189-336) ----
+ * mean (WITHOUT meant), sigma2 and rest as in _get_sigma2_and_variance_rest; var = sigma2 + rest.
+ * Sigma is the full d x d matrix (diagonal used for the J term, full for tr(H Sigma)). */
+int gpx_propagate_approx(gpx_handle *h, const double *u, const double *Sigma,
+                         double *mean, double *var, double *sigma2, double *rest);
+
+/* ---- a13: UncertaintyPropagationApprox._get_variance_dv_h for every h in [0,d)
+ * (skgpuppy/UncertaintyPropagation.py:564-630, UncertaintyPropagation2.pyx:340-380) ---- */
+int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out /* [d] */);
+
+/* ---- a14: UncertaintyPropagationExact.propagate_GA / propagate_mean
+ * (skgpuppy/UncertaintyPropagation.py:246-379, UncertaintyPropagation2.pyx:57-184) ----
+ * mean WITHOUT meant; var = (v+vt) - sum_ij (Kinv_ij - beta_i beta_j) L_ij - mean^2. */
+int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var);
+int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean);
+
+/* ---- measurement: per-kernel-class GPU timings taken with HIP events on the handle's stream ----
+ * gpx_profile_enable(h,1) brackets every launch of the listed kernel classes with an event pair;
+ * gpx_profile_read sums them (it synchronises the stream).  work = algorithmic flops (GEMM, POTRF,
+ * EXACT) or bytes (others) as defined in DESIGN.md. */
+enum {
+    GPX_K_GRAM = 0,      /* Gram / cross-covariance assembly             (bytes) */
+    GPX_K_GEMM = 1,      /* fp64 MFMA GEMM/SYRK/TRSM-leaf tiles           (flops) */
+    GPX_K_POTRF_LEAF = 2,/* 128x128 diagonal-block factor + inverse       (flops) */
+    GPX_K_TRSV = 3,      /* blocked triangular solves for alpha           (bytes) */
+    GPX_K_REDUCE = 4,    /* predictive mean/variance row reductions       (bytes) */
+    GPX_K_QUAD = 5,      /* Kinv x V pass of propagate (approx)           (bytes) */
+    GPX_K_EXACT = 6,     /* Girard l_i / L_ij double sum                  (flops) */
+    GPX_K_COUNT = 7
+};
+int gpx_profile_enable(gpx_handle *h, int on);
+int gpx_profile_reset(gpx_handle *h);
+int gpx_profile_read(gpx_handle *h, int kernel_class, int64_t *launches, double *total_ms, double *total_work);
+
+/* ---- device micro-benchmarks used to re-verify the roofline denominators on the box ---- */
+int gpx_bench_mfma_f64(int iters, double *tflops);          /* back-to-back v_mfma_f64_16x16x4_f64 */
+int gpx_bench_hbm(int64_t bytes, int iters, double *write_gbs, double *copy_gbs);
+
+/* ---- building blocks on device pointers (used by the multi-GPU host and by tests) ----
+ * All pointers are DEVICE pointers; leading dimensions in elements; sizes multiples of GPX_TILE. */
+int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_dev, int64_t n2, int d, const double *theta,
+                 double add_diag, int lower_only, int pad_identity,
+                 double *out_dev, int64_t ld, int64_t rows_pad, int64_t cols_pad, void *stream);
+/* C = alpha * A B^T + beta * C  with A[M,K], B[N,K]; lower_only skips tiles above the diagonal */
+int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream);
+/* factor one 128x128 diagonal block in place (lower) and write its inverse to dinv[128*128];
+ * info_dev: device int, set to 1-based failing column + col_offset on a non-positive pivot */
+int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

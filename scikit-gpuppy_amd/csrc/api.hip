@@ -1,0 +1,757 @@
+// api.hip -- the C-ABI of libgpx (include/gpx.h): handle management and host-side orchestration.
+// Every entry point returns an int status; no exception crosses the boundary; there is no CPU
+// fallback (a missing/unsupported device is an error, never a silent host computation).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.h"
+
+// launchers living in propagate.hip
+int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
+int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
+                     const double *bT, const double *e, const double *F, double *partial, double *out_dev, hipStream_t s,
+                     Profiler *prof);
+int launch_approx_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev, double v,
+                        double vt, double *VM, double *AUX, double *cplain, hipStream_t s);
+int launch_trace(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
+                 const double *Sigma_dev, const double *cplain, double *tr, hipStream_t s);
+int launch_cjh(const double *x, int64_t n, int d, const double *u_dev, const double *w_dev, double v, double vt, double *C,
+               double *J, double *H, hipStream_t s);
+int launch_exact_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
+                       const double *Ls_dev, const double *dinv_diag_dev, double v, double vt, double nc1, double *aT,
+                       double *bT, double *e, double *F, double *lm, hipStream_t s);
+
+// ---- error text -----------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int g_device = 0;
+
+void gpx_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *gpx_last_error(void) { return g_err; }
+extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
+
+extern "C" int gpx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gpx_set_device(int device)
+{
+    int n = gpx_device_count();
+    if (device < 0 || device >= n) {
+        gpx_set_error("gpx_set_device: device %d not available (%d visible)", device, n);
+        return n == 0 ? GPX_ERR_NO_DEVICE : GPX_ERR_BAD_ARG;
+    }
+    g_device = device;
+    return 0;
+}
+
+static int require_device()
+{
+    int n = gpx_device_count();
+    if (n == 0) {
+        gpx_set_error("no HIP device visible: libgpx has no CPU fallback");
+        return GPX_ERR_NO_DEVICE;
+    }
+    if (g_device >= n) g_device = 0;
+    GPX_HIP(hipSetDevice(g_device));
+    hipDeviceProp_t prop;
+    GPX_HIP(hipGetDeviceProperties(&prop, g_device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        gpx_set_error("device %d is %s; libgpx is built for gfx950 (MI355X) only", g_device, prop.gcnArchName);
+        return GPX_ERR_NO_DEVICE;
+    }
+    return 0;
+}
+
+// ---- profiler ----------------------------------------------------------------------------------
+int Profiler::begin(hipStream_t s, int cls, double w)
+{
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!pool.empty()) {
+        ev = pool.back();
+        pool.pop_back();
+    } else {
+        if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return -1;
+    }
+    if (hipEventRecord(ev.first, s) != hipSuccess) return -1;
+    recs.push_back({cls, w, ev.first, ev.second});
+    return (int)recs.size() - 1;
+}
+void Profiler::end(hipStream_t s, int idx) { (void)hipEventRecord(recs[idx].b, s); }
+int Profiler::collect(hipStream_t s)
+{
+    if (hipStreamSynchronize(s) != hipSuccess) return GPX_ERR_HIP;
+    for (auto &r : recs) {
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+            launches[r.cls] += 1;
+            ms[r.cls] += t;
+            work[r.cls] += r.work;
+        }
+        pool.push_back({r.a, r.b});
+    }
+    recs.clear();
+    return 0;
+}
+void Profiler::reset()
+{
+    for (auto &r : recs) pool.push_back({r.a, r.b});
+    recs.clear();
+    for (int i = 0; i < GPX_K_COUNT; ++i) { launches[i] = 0; ms[i] = 0; work[i] = 0; }
+}
+void Profiler::destroy()
+{
+    reset();
+    for (auto &p : pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    pool.clear();
+}
+
+// ---- helpers -----------------------------------------------------------------------------------
+static int dalloc(double **p, int64_t elems)
+{
+    *p = nullptr;
+    if (elems <= 0) elems = 1;
+    GPX_HIP(hipMalloc((void **)p, sizeof(double) * (size_t)elems));
+    return 0;
+}
+
+static int parse_theta(const double *theta, int d, double *v, double *vt, double *w)
+{
+    if (!theta || d < 1 || d > GPX_MAX_D) {
+        gpx_set_error("bad theta / d=%d (1..%d supported)", d, GPX_MAX_D);
+        return GPX_ERR_BAD_ARG;
+    }
+    *v = exp(theta[0]);
+    *vt = exp(theta[1]);   // theta[1] = -inf gives vt = 0 (appears in the reference's tests)
+    for (int k = 0; k < d; ++k) w[k] = exp(theta[2 + k]);
+    if (!(*v > 0.0) || !isfinite(*v) || !isfinite(*vt)) {
+        gpx_set_error("theta gives v=%g vt=%g", *v, *vt);
+        return GPX_ERR_BAD_ARG;
+    }
+    for (int k = 0; k < d; ++k)
+        if (!(w[k] >= 0.0) || !isfinite(w[k])) {
+            gpx_set_error("theta gives w[%d]=%g", k, w[k]);
+            return GPX_ERR_BAD_ARG;
+        }
+    return 0;
+}
+
+static int ensure_Z(gpx_handle *h, int64_t rows)
+{
+    if (h->zrows >= rows && h->Z) return 0;
+    if (h->Z) { (void)hipFree(h->Z); h->Z = nullptr; h->zrows = 0; }
+    GPX_TRY(dalloc(&h->Z, rows * h->npad));
+    h->zrows = rows;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void extract_lower_kernel(const double *L, long ld, long n, double *out, long ldo)
+{
+    const long i = blockIdx.x;
+    for (long j = threadIdx.x; j < n; j += 256) out[i * ldo + j] = (j <= i) ? L[i * ld + j] : 0.0;
+}
+
+// ---- Gram (stand-alone) --------------------------------------------------------------------------
+extern "C" int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_dev, int64_t n2, int d, const double *theta,
+                            double add_diag, int lower_only, int pad_identity, double *out_dev, int64_t ld,
+                            int64_t rows_pad, int64_t cols_pad, void *stream)
+{
+    GPX_TRY(require_device());
+    double v, vt, w[GPX_MAX_D], sw[GPX_MAX_D];
+    GPX_TRY(parse_theta(theta, d, &v, &vt, w));
+    if (n1 < 0 || n2 < 0 || !out_dev) { gpx_set_error("gpx_dev_gram: bad sizes"); return GPX_ERR_BAD_ARG; }
+    for (int k = 0; k < d; ++k) sw[k] = sqrt(w[k]);
+    hipStream_t s = (hipStream_t)stream;
+    double *swd = nullptr, *a = nullptr, *b = nullptr;
+    GPX_TRY(dalloc(&swd, d));
+    GPX_HIP(hipMemcpyAsync(swd, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    GPX_TRY(dalloc(&a, std::max<int64_t>(n1, 1) * d));
+    GPX_TRY(launch_scale_rows(xi_dev, n1, n1, d, swd, a, s));
+    if (xj_dev == xi_dev && n1 == n2) b = a;
+    else {
+        GPX_TRY(dalloc(&b, std::max<int64_t>(n2, 1) * d));
+        GPX_TRY(launch_scale_rows(xj_dev, n2, n2, d, swd, b, s));
+    }
+    int rc = launch_gram(a, n1, b, n2, d, v, add_diag, lower_only, pad_identity ? 2 : 1, out_dev, ld, rows_pad, cols_pad, s, nullptr);
+    hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(swd);
+    (void)hipFree(a);
+    if (b != a) (void)hipFree(b);
+    if (rc) return rc;
+    GPX_HIP(e);
+    return 0;
+}
+
+extern "C" int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t n2, int d, const double *theta,
+                        double add_diag, double *K_out)
+{
+    GPX_TRY(require_device());
+    if (!xi || !xj || !K_out || n1 < 0 || n2 < 0) { gpx_set_error("gpx_gram: null pointer / negative size"); return GPX_ERR_BAD_ARG; }
+    if (n1 == 0 || n2 == 0) return 0;
+    double v, vt, w[GPX_MAX_D];
+    GPX_TRY(parse_theta(theta, d, &v, &vt, w));
+    const int64_t rp = round_up(n1, TILE), cp = round_up(n2, TILE);
+    double *a = nullptr, *b = nullptr, *out = nullptr;
+    int rc = 0;
+    do {
+        if ((rc = dalloc(&a, n1 * d))) break;
+        if (hipMemcpy(a, xi, sizeof(double) * n1 * d, hipMemcpyDefault) != hipSuccess) { gpx_set_error("copy xi failed"); rc = GPX_ERR_HIP; break; }
+        const bool same = (xj == xi && n1 == n2);
+        if (same) b = a;
+        else {
+            if ((rc = dalloc(&b, n2 * d))) break;
+            if (hipMemcpy(b, xj, sizeof(double) * n2 * d, hipMemcpyDefault) != hipSuccess) { gpx_set_error("copy xj failed"); rc = GPX_ERR_HIP; break; }
+        }
+        if ((rc = dalloc(&out, rp * cp))) break;
+        if ((rc = gpx_dev_gram(a, n1, b, n2, d, theta, add_diag, 0, 0, out, cp, rp, cp, nullptr))) break;
+        if (hipMemcpy2D(K_out, sizeof(double) * n2, out, sizeof(double) * cp, sizeof(double) * n2, n1, hipMemcpyDefault) != hipSuccess) {
+            gpx_set_error("copy K_out failed");
+            rc = GPX_ERR_HIP;
+        }
+    } while (0);
+    if (b && b != a) (void)hipFree(b);
+    if (a) (void)hipFree(a);
+    if (out) (void)hipFree(out);
+    return rc;
+}
+
+// ---- fit ---------------------------------------------------------------------------------------
+extern "C" void gpx_free(gpx_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->prof.destroy();
+    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
+    for (double *p : bufs)
+        if (p) (void)hipFree(p);
+    if (h->info_dev) (void)hipFree(h->info_dev);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int factor_once(gpx_handle *h, double add_diag, int *info_host)
+{
+    hipStream_t s = h->stream;
+    GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
+    GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, &h->prof));
+    GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
+                       gpx_handle **out)
+{
+    if (out) *out = nullptr;
+    GPX_TRY(require_device());
+    if (!x || !t_centered || !out || n < 1) { gpx_set_error("gpx_fit: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
+    gpx_handle *h = new (std::nothrow) gpx_handle();
+    if (!h) { gpx_set_error("out of host memory"); return GPX_ERR_HIP; }
+    h->device = g_device;
+    int rc = parse_theta(theta, d, &h->v, &h->vt, h->w);
+    if (rc) { delete h; return rc; }
+    memcpy(h->theta, theta, sizeof(double) * (d + 2));
+    h->n = n;
+    h->d = d;
+    h->npad = round_up(n, TILE);
+    h->nblk = h->npad / TILE;
+    if (stream) h->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
+        h->own_stream = true;
+    }
+    hipStream_t s = h->stream;
+    auto fail = [&](int code) { gpx_free(h); return code; };
+
+    double sw[GPX_MAX_D];
+    for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
+    if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
+        (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->L, h->npad * h->npad)) ||
+        (rc = dalloc(&h->Dinv, h->nblk * (int64_t)TILE * TILE)) || (rc = dalloc(&h->diagL, h->npad)) ||
+        (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) || (rc = dalloc(&h->alpha, h->npad)) ||
+        (rc = dalloc(&h->small, 4096 + h->npad)))
+        return fail(rc);
+    h->small_elems = 4096 + h->npad;
+    if (hipMalloc((void **)&h->info_dev, sizeof(int)) != hipSuccess) { gpx_set_error("hipMalloc info failed"); return fail(GPX_ERR_HIP); }
+
+#define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
+    FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
+    FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    FIT_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * h->npad, s));
+    FIT_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
+    FIT_HIP(hipStreamSynchronize(s));   // sw / h->w are stack/handle memory: make the copies complete before returning paths
+    if ((rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
+
+    int info = 0;
+    if ((rc = factor_once(h, h->vt, &info))) return fail(rc);
+    if (info > 0) {
+        // reference fallback: cholesky(K + 1e-5 I)   (skgpuppy/Covariance.py:180-185)
+        h->jitter = 1e-5;
+        if ((rc = factor_once(h, h->vt + h->jitter, &info))) return fail(rc);
+        if (info > 0) {
+            gpx_set_error("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter", info);
+            return fail(info);
+        }
+    }
+    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
+    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
+    FIT_HIP(hipStreamSynchronize(s));
+#undef FIT_HIP
+    *out = h;
+    return 0;
+}
+
+#define CHECK_H(h)                                                  \
+    do {                                                            \
+        if (!(h)) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; } \
+        GPX_HIP(hipSetDevice((h)->device));                         \
+    } while (0)
+
+extern "C" int gpx_n(const gpx_handle *h, int64_t *n, int *d)
+{
+    if (!h) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; }
+    if (n) *n = h->n;
+    if (d) *d = h->d;
+    return 0;
+}
+
+extern "C" int gpx_jitter_used(const gpx_handle *h, double *jitter)
+{
+    if (!h || !jitter) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    *jitter = h->jitter;
+    return 0;
+}
+
+extern "C" int gpx_logdet(gpx_handle *h, double *logdet)
+{
+    CHECK_H(h);
+    if (!logdet) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    if (!h->have_logdet) {
+        GPX_TRY(launch_logdet(h->diagL, h->n, h->small, h->stream));
+        GPX_HIP(hipMemcpyAsync(&h->logdet, h->small, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        GPX_HIP(hipStreamSynchronize(h->stream));
+        h->have_logdet = true;
+    }
+    *logdet = h->logdet;
+    return 0;
+}
+
+// ---- predict -----------------------------------------------------------------------------------
+extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *mean_out, double *var_out)
+{
+    CHECK_H(h);
+    if (m < 0 || (m > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (m == 0) return 0;
+    hipStream_t s = h->stream;
+    const int d = h->d;
+    int64_t cap = ((int64_t)8 << 30) / (h->npad * (int64_t)sizeof(double));
+    cap = std::max<int64_t>(TILE, cap / TILE * TILE);
+    cap = std::min<int64_t>(cap, 32768);
+    const int64_t chunk = std::min<int64_t>(round_up(m, TILE), cap);
+    GPX_TRY(ensure_Z(h, chunk));
+    double *xq = nullptr, *xqw = nullptr, *mv = nullptr;
+    GPX_TRY(dalloc(&xq, chunk * d));
+    int rc = 0;
+    if ((rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) { (void)hipFree(xq); if (xqw) (void)hipFree(xqw); return rc; }
+    for (int64_t m0 = 0; m0 < m && rc == 0; m0 += chunk) {
+        const int64_t mc = std::min<int64_t>(chunk, m - m0), mp = round_up(mc, TILE);
+        hipError_t e = hipMemcpyAsync(xq, xs + m0 * d, sizeof(double) * mc * d, hipMemcpyDefault, s);
+        if (e != hipSuccess) { gpx_set_error("copy xs failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
+        if ((rc = launch_scale_rows(xq, mc, mp, d, h->sw, xqw, s))) break;
+        // kv = cross-covariance (no vt), zero padded: rows >= mc and columns >= n are 0
+        if ((rc = launch_gram(xqw, mc, h->xs_w, h->n, d, h->v, 0.0, 0, 1, h->Z, h->npad, mp, h->npad, s, &h->prof))) break;
+        // Z <- kv L^-T  : row m of Z is (L^-1 kv_m)^T
+        if ((rc = trsm_right_lt(h->Z, h->npad, mp, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof))) break;
+        // var = v + vt - |z|^2 ; mean = z . y   (k includes vt: GaussianProcess.py:75,78)
+        if ((rc = launch_predict_reduce(h->Z, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof))) break;
+        e = hipMemcpyAsync(mean_out + m0, mv, sizeof(double) * mc, hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(var_out + m0, mv + chunk, sizeof(double) * mc, hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { gpx_set_error("predict copy-out failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(xq);
+    (void)hipFree(xqw);
+    (void)hipFree(mv);
+    return rc;
+}
+
+// ---- accessors -----------------------------------------------------------------------------------
+extern "C" int gpx_alpha(gpx_handle *h, double *beta_out)
+{
+    CHECK_H(h);
+    if (!beta_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    GPX_HIP(hipMemcpyAsync(beta_out, h->alpha, sizeof(double) * h->n, hipMemcpyDefault, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+static int ensure_kinv(gpx_handle *h)
+{
+    if (h->Kinv) return 0;
+    hipStream_t s = h->stream;
+    GPX_TRY(ensure_Z(h, h->npad));
+    double *K = nullptr;
+    GPX_TRY(dalloc(&K, h->npad * h->npad));
+    int rc = 0;
+    // Z = I ; Z <- Z L^-T = L^-T ; Kinv = Z Z^T = L^-T L^-1 (lower tiles, then mirrored)
+    if ((rc = launch_set_identity(h->Z, h->npad, h->npad, s)) ||
+        (rc = trsm_right_lt(h->Z, h->npad, h->npad, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof)) ||
+        (rc = launch_gemm_nt(h->Z, h->npad, h->Z, h->npad, K, h->npad, h->npad, h->npad, h->npad, 1.0, 0.0, 1, s, &h->prof)) ||
+        (rc = launch_symmetrize_lower(K, h->npad, h->npad, s))) {
+        (void)hipFree(K);
+        return rc;
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(K); gpx_set_error("Kinv build failed: %s", hipGetErrorString(e)); return GPX_ERR_HIP; }
+    h->Kinv = K;
+    return 0;
+}
+
+extern "C" int gpx_kinv(gpx_handle *h, double *Kinv_out)
+{
+    CHECK_H(h);
+    if (!Kinv_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    GPX_TRY(ensure_kinv(h));
+    GPX_HIP(hipMemcpy2DAsync(Kinv_out, sizeof(double) * h->n, h->Kinv, sizeof(double) * h->npad, sizeof(double) * h->n, h->n,
+                             hipMemcpyDefault, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+extern "C" int gpx_chol(gpx_handle *h, double *L_out)
+{
+    CHECK_H(h);
+    if (!L_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    double *tmp = nullptr;
+    GPX_TRY(dalloc(&tmp, h->n * h->n));
+    hipLaunchKernelGGL(extract_lower_kernel, dim3((unsigned)h->n), dim3(256), 0, h->stream, (const double *)h->L,
+                       (long)h->npad, (long)h->n, tmp, (long)h->n);
+    hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * h->n * h->n, hipMemcpyDefault, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    GPX_HIP(e);
+    return 0;
+}
+
+// ---- propagation -----------------------------------------------------------------------------------
+// layout of h->V: [128][npad] rows 0 = C, 1..d = J_k (rest zero, so the block is one GEMM row tile)
+// layout of h->KV: [128][npad] = V Kinv ; followed by AUX [(d+1)][npad] (row 0 tr, rows 1..d H_kk),
+//                  cplain[npad], udev[GPX_MAX_D], Sigma[GPX_MAX_D^2], out[256]
+static inline double *aux_ptr(gpx_handle *h) { return h->KV + (int64_t)TILE * h->npad; }
+static inline double *cplain_ptr(gpx_handle *h) { return aux_ptr(h) + (int64_t)(h->d + 1) * h->npad; }
+static inline double *udev_ptr(gpx_handle *h) { return cplain_ptr(h) + h->npad; }
+static inline double *sigma_ptr(gpx_handle *h) { return udev_ptr(h) + GPX_MAX_D; }
+static inline double *out_ptr(gpx_handle *h) { return sigma_ptr(h) + GPX_MAX_D * GPX_MAX_D; }
+
+static int ensure_prop_buffers(gpx_handle *h)
+{
+    if (h->V) return 0;
+    GPX_TRY(dalloc(&h->V, (int64_t)TILE * h->npad));
+    GPX_HIP(hipMemsetAsync(h->V, 0, sizeof(double) * TILE * h->npad, h->stream));
+    GPX_TRY(dalloc(&h->KV, (int64_t)TILE * h->npad + (int64_t)(h->d + 2) * h->npad + GPX_MAX_D + GPX_MAX_D * GPX_MAX_D + 256));
+    return 0;
+}
+
+static int prepare_u(gpx_handle *h, const double *u)
+{
+    GPX_TRY(ensure_kinv(h));
+    GPX_TRY(ensure_prop_buffers(h));
+    double uh[GPX_MAX_D];
+    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * h->d, hipMemcpyDefault));
+    if (h->have_u && memcmp(uh, h->u, sizeof(double) * h->d) == 0) return 0;
+    hipStream_t s = h->stream;
+    h->have_u = false;
+    GPX_HIP(hipMemcpyAsync(udev_ptr(h), uh, sizeof(double) * h->d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
+    GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
+    // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6
+    {
+        ProfScope ps(&h->prof, s, GPX_K_QUAD, 8.0 * (double)h->npad * (double)h->npad);
+        GPX_TRY(launch_gemm_nt(h->V, h->npad, h->Kinv, h->npad, h->KV, h->npad, TILE, h->npad, h->npad, 1.0, 0.0, 0, s, nullptr));
+    }
+    memcpy(h->u, uh, sizeof(double) * h->d);
+    h->have_u = true;
+    return 0;
+}
+
+extern "C" int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, double *H)
+{
+    CHECK_H(h);
+    if (!u) { gpx_set_error("null u"); return GPX_ERR_BAD_ARG; }
+    const int64_t n = h->n;
+    const int d = h->d;
+    hipStream_t s = h->stream;
+    double *ud = nullptr, *buf = nullptr;
+    GPX_TRY(dalloc(&ud, d));
+    int rc = dalloc(&buf, n * (1 + d + (int64_t)d * d));
+    if (rc) { (void)hipFree(ud); return rc; }
+    hipError_t e = hipMemcpy(ud, u, sizeof(double) * d, hipMemcpyDefault);
+    double *Cd = buf, *Jd = buf + n, *Hd = Jd + n * d;
+    if (e == hipSuccess) {
+        rc = launch_cjh(h->x, n, d, ud, h->wdev, h->v, h->vt, C ? Cd : nullptr, J ? Jd : nullptr, H ? Hd : nullptr, s);
+        if (!rc && C) e = hipMemcpyAsync(C, Cd, sizeof(double) * n, hipMemcpyDefault, s);
+        if (!rc && e == hipSuccess && J) e = hipMemcpyAsync(J, Jd, sizeof(double) * n * d, hipMemcpyDefault, s);
+        if (!rc && e == hipSuccess && H) e = hipMemcpyAsync(H, Hd, sizeof(double) * n * d * d, hipMemcpyDefault, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    (void)hipFree(ud);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    GPX_HIP(e);
+    return 0;
+}
+
+extern "C" int gpx_propagate_approx(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var,
+                                    double *sigma2, double *rest)
+{
+    CHECK_H(h);
+    if (!u || !Sigma) { gpx_set_error("null u / Sigma"); return GPX_ERR_BAD_ARG; }
+    const int d = h->d;
+    const int64_t np = h->npad;
+    hipStream_t s = h->stream;
+    GPX_TRY(prepare_u(h, u));
+    double Sh[GPX_MAX_D * GPX_MAX_D];
+    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpyAsync(sigma_ptr(h), Sh, sizeof(double) * d * d, hipMemcpyHostToDevice, s));
+    double *tr = aux_ptr(h);
+    GPX_TRY(launch_trace(h->x, h->n, np, d, udev_ptr(h), h->wdev, sigma_ptr(h), cplain_ptr(h), tr, s));
+    // dots: 0 beta.C  1 beta.tr  2 C.KinvC  3 KinvC.tr  then per k: J_k.KinvJ_k , beta.J_k
+    std::vector<std::pair<const double *, const double *>> pr;
+    const double *C = h->V, *KC = h->KV;
+    pr.push_back({h->alpha, C});
+    pr.push_back({h->alpha, tr});
+    pr.push_back({C, KC});
+    pr.push_back({KC, tr});
+    for (int k = 0; k < d; ++k) {
+        pr.push_back({h->V + (int64_t)(k + 1) * np, h->KV + (int64_t)(k + 1) * np});
+        pr.push_back({h->alpha, h->V + (int64_t)(k + 1) * np});
+    }
+    GPX_TRY(launch_dot_pairs(pr, np, out_ptr(h), s));
+    double o[4 + 2 * GPX_MAX_D];
+    GPX_HIP(hipMemcpyAsync(o, out_ptr(h), sizeof(double) * pr.size(), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    const double mu = o[0] + 0.5 * o[1];                      // UncertaintyPropagation.py:397-408
+    const double s2 = (h->v + h->vt) - o[2];                  // :412-433  (C(u,u) = v + vt)
+    double var2 = 0.0;                                        // :435-460
+    for (int k = 0; k < d; ++k) var2 += Sh[k * d + k] * (o[4 + 2 * k] - o[5 + 2 * k] * o[5 + 2 * k]);
+    var2 = -var2;
+    const double var3 = -o[3];                                // :464-479 with Kinv symmetric
+    if (mean) *mean = mu;
+    if (sigma2) *sigma2 = s2;
+    if (rest) *rest = var2 + var3;
+    if (var) *var = s2 + var2 + var3;
+    return 0;
+}
+
+extern "C" int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out)
+{
+    CHECK_H(h);
+    if (!u || !dvh_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    const int d = h->d;
+    const int64_t np = h->npad;
+    hipStream_t s = h->stream;
+    GPX_TRY(prepare_u(h, u));
+    std::vector<std::pair<const double *, const double *>> pr;
+    for (int k = 0; k < d; ++k) {
+        pr.push_back({h->V + (int64_t)(k + 1) * np, h->KV + (int64_t)(k + 1) * np});   // J_k Kinv J_k
+        pr.push_back({h->alpha, h->V + (int64_t)(k + 1) * np});                        // beta . J_k
+        pr.push_back({h->KV, aux_ptr(h) + (int64_t)(k + 1) * np});                     // (Kinv C) . H_kk
+    }
+    GPX_TRY(launch_dot_pairs(pr, np, out_ptr(h), s));
+    double o[3 * GPX_MAX_D];
+    GPX_HIP(hipMemcpyAsync(o, out_ptr(h), sizeof(double) * pr.size(), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < d; ++k) {
+        const double v2 = -(o[3 * k] - o[3 * k + 1] * o[3 * k + 1]);   // UncertaintyPropagation.py:593-607
+        const double v3 = -o[3 * k + 2];                               // :614-627
+        double r = v2 + v3;
+        GPX_HIP(hipMemcpy(dvh_out + k, &r, sizeof(double), hipMemcpyDefault));
+    }
+    return 0;
+}
+
+// small dense inverse (Gauss-Jordan, partial pivoting) for (W/2 + Sigma), d <= 64
+static int small_inverse(const double *A, int d, double *inv)
+{
+    std::vector<double> M((size_t)d * 2 * d);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) { M[(size_t)i * 2 * d + j] = A[i * d + j]; M[(size_t)i * 2 * d + d + j] = (i == j); }
+    for (int c = 0; c < d; ++c) {
+        int p = c;
+        for (int r = c + 1; r < d; ++r)
+            if (fabs(M[(size_t)r * 2 * d + c]) > fabs(M[(size_t)p * 2 * d + c])) p = r;
+        if (M[(size_t)p * 2 * d + c] == 0.0) return -1;
+        if (p != c)
+            for (int j = 0; j < 2 * d; ++j) std::swap(M[(size_t)p * 2 * d + j], M[(size_t)c * 2 * d + j]);
+        const double piv = M[(size_t)c * 2 * d + c];
+        for (int j = 0; j < 2 * d; ++j) M[(size_t)c * 2 * d + j] /= piv;
+        for (int r = 0; r < d; ++r)
+            if (r != c) {
+                const double f = M[(size_t)r * 2 * d + c];
+                if (f != 0.0)
+                    for (int j = 0; j < 2 * d; ++j) M[(size_t)r * 2 * d + j] -= f * M[(size_t)c * 2 * d + j];
+            }
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) inv[i * d + j] = M[(size_t)i * 2 * d + d + j];
+    return 0;
+}
+
+static int exact_common(gpx_handle *h, const double *u, const double *Sigma, bool want_var, double *mean, double *var)
+{
+    const int d = h->d;
+    const int64_t np = h->npad;
+    hipStream_t s = h->stream;
+    if (want_var) GPX_TRY(ensure_kinv(h));
+    GPX_TRY(ensure_prop_buffers(h));
+    double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
+    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    // constants (UncertaintyPropagation.py:247-257, :292-303); Winv of the reference holds w
+    std::vector<double> A((size_t)d * d), Ai((size_t)d * d), Ls((size_t)d * d), dd(d);
+    double nc1 = 1.0, nc2 = 1.0;
+    for (int k = 0; k < d; ++k) {
+        const double wk = h->w[k], sk = Sh[k * d + k];
+        dd[k] = wk - wk / (1.0 + wk * sk);
+        nc1 *= (1.0 + wk * sk);
+        nc2 *= (2.0 * wk * sk + 1.0);
+    }
+    nc1 = 1.0 / sqrt(nc1);
+    nc2 = 1.0 / sqrt(nc2);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) A[(size_t)i * d + j] = Sh[i * d + j] + (i == j ? 0.5 / h->w[i] : 0.0);
+    if (small_inverse(A.data(), d, Ai.data())) { gpx_set_error("W/2 + Sigma is singular"); return GPX_ERR_BAD_ARG; }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            const double lij = (i == j ? 2.0 * h->w[i] : 0.0) - Ai[(size_t)i * d + j];
+            const double lji = (i == j ? 2.0 * h->w[i] : 0.0) - Ai[(size_t)j * d + i];
+            Ls[(size_t)i * d + j] = 0.5 * (lij + lji);     // only the symmetric part enters z^T Lambda^-1 z
+        }
+    // device scratch: reuse Z-independent buffer: aT[d][np], bT[d][np], e, F, lm, partial[np/16], consts
+    double *buf = nullptr;
+    const int64_t need = (2 * (int64_t)d + 4) * np + (int64_t)d * d + 2 * d + 8;
+    GPX_TRY(dalloc(&buf, need));
+    double *aT = buf, *bT = aT + (int64_t)d * np, *e = bT + (int64_t)d * np, *F = e + np, *lm = F + np, *partial = lm + np;
+    double *Lsd = partial + np, *ddd = Lsd + (int64_t)d * d, *ud = ddd + d, *outd = ud + d;
+    int rc = 0;
+    hipError_t er = hipMemcpyAsync(Lsd, Ls.data(), sizeof(double) * d * d, hipMemcpyHostToDevice, s);
+    if (er == hipSuccess) er = hipMemcpyAsync(ddd, dd.data(), sizeof(double) * d, hipMemcpyHostToDevice, s);
+    if (er == hipSuccess) er = hipMemcpyAsync(ud, uh, sizeof(double) * d, hipMemcpyHostToDevice, s);
+    if (er != hipSuccess) { (void)hipFree(buf); gpx_set_error("exact: constant upload failed"); return GPX_ERR_HIP; }
+    rc = launch_exact_build(h->x, h->n, np, d, ud, h->wdev, Lsd, ddd, h->v, h->vt, nc1, aT, bT, e, F, lm, s);
+    std::vector<std::pair<const double *, const double *>> pr;
+    pr.push_back({h->alpha, lm});
+    if (!rc) rc = launch_dot_pairs(pr, np, outd, s);
+    if (!rc && want_var) rc = launch_exact_sum(h->Kinv, np, np, d, h->alpha, aT, bT, e, F, partial, outd + 1, s, &h->prof);
+    double o[2] = {0, 0};
+    if (!rc) {
+        er = hipMemcpyAsync(o, outd, sizeof(double) * 2, hipMemcpyDeviceToHost, s);
+        if (er == hipSuccess) er = hipStreamSynchronize(s);
+        if (er != hipSuccess) { gpx_set_error("exact: %s", hipGetErrorString(er)); rc = GPX_ERR_HIP; }
+    } else (void)hipStreamSynchronize(s);
+    (void)hipFree(buf);
+    if (rc) return rc;
+    const double mu = o[0];
+    if (mean) *mean = mu;
+    if (want_var && var) *var = (h->v + h->vt) - nc2 * o[1] - mu * mu;   // UncertaintyPropagation.py:377
+    return 0;
+}
+
+extern "C" int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var)
+{
+    CHECK_H(h);
+    if (!u || !Sigma) { gpx_set_error("null u / Sigma"); return GPX_ERR_BAD_ARG; }
+    return exact_common(h, u, Sigma, true, mean, var);
+}
+
+extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean)
+{
+    CHECK_H(h);
+    if (!u || !Sigma || !mean) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    return exact_common(h, u, Sigma, false, mean, nullptr);
+}
+
+// ---- profiling ---------------------------------------------------------------------------------
+extern "C" int gpx_profile_enable(gpx_handle *h, int on)
+{
+    if (!h) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; }
+    h->prof.on = on != 0;
+    return 0;
+}
+extern "C" int gpx_profile_reset(gpx_handle *h)
+{
+    if (!h) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; }
+    h->prof.reset();
+    return 0;
+}
+extern "C" int gpx_profile_read(gpx_handle *h, int cls, int64_t *launches, double *total_ms, double *total_work)
+{
+    CHECK_H(h);
+    if (cls < 0 || cls >= GPX_K_COUNT) { gpx_set_error("bad kernel class"); return GPX_ERR_BAD_ARG; }
+    GPX_TRY(h->prof.collect(h->stream));
+    if (launches) *launches = h->prof.launches[cls];
+    if (total_ms) *total_ms = h->prof.ms[cls];
+    if (total_work) *total_work = h->prof.work[cls];
+    return 0;
+}
+
+// ---- HBM micro-benchmark -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hbm_fill_kernel(v2d *p, long n16)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) p[i] = (v2d){1.0, 2.0};
+}
+__global__ __launch_bounds__(256) void hbm_copy_kernel(const v2d *__restrict__ a, v2d *__restrict__ b, long n16)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) b[i] = a[i];
+}
+
+extern "C" int gpx_bench_hbm(int64_t bytes, int iters, double *write_gbs, double *copy_gbs)
+{
+    GPX_TRY(require_device());
+    if (bytes < (1 << 20) || iters < 1) { gpx_set_error("gpx_bench_hbm: bytes >= 1 MiB, iters >= 1"); return GPX_ERR_BAD_ARG; }
+    const long n16 = bytes / 16;
+    v2d *a = nullptr, *b = nullptr;
+    GPX_HIP(hipMalloc((void **)&a, n16 * 16));
+    if (hipMalloc((void **)&b, n16 * 16) != hipSuccess) { (void)hipFree(a); gpx_set_error("hipMalloc failed"); return GPX_ERR_HIP; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms = 0;
+    hipLaunchKernelGGL(hbm_fill_kernel, dim3(2048), dim3(256), 0, 0, a, n16);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(hbm_fill_kernel, dim3(2048), dim3(256), 0, 0, a, n16);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (write_gbs) *write_gbs = (double)n16 * 16 * iters / (ms * 1e-3) / 1e9;
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, 0, (const v2d *)a, b, n16);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(hbm_copy_kernel, dim3(2048), dim3(256), 0, 0, (const v2d *)a, b, n16);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (copy_gbs) *copy_gbs = 2.0 * (double)n16 * 16 * iters / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return 0;
+}

@@ -1,0 +1,127 @@
+// common.h -- shared declarations of libgpx (gfx950 only; no other target is supported)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int TILE = GPX_TILE;       // 128: diagonal-block size, GEMM block tile
+constexpr int GEMM_BK = 16;          // k-depth of one LDS stage
+constexpr int GEMM_LDS_S = 18;       // padded LDS row stride in doubles (S/2 odd -> conflict-free ds_read_b64 fragments)
+
+// ---- error plumbing ---------------------------------------------------------------------
+void gpx_set_error(const char *fmt, ...);
+#define GPX_HIP(call)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            gpx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GPX_ERR_HIP;                                                             \
+        }                                                                                   \
+    } while (0)
+#define GPX_TRY(call)            \
+    do {                         \
+        int r_ = (call);         \
+        if (r_ != 0) return r_;  \
+    } while (0)
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ---- per-kernel-class event profiler ---------------------------------------------------------
+struct Profiler {
+    bool on = false;
+    struct Rec { int cls; double work; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    int64_t launches[GPX_K_COUNT] = {0};
+    double ms[GPX_K_COUNT] = {0};
+    double work[GPX_K_COUNT] = {0};
+    int begin(hipStream_t s, int cls, double w);   // returns record index or -1
+    void end(hipStream_t s, int idx);
+    int collect(hipStream_t s);                    // synchronises, folds recs into the sums
+    void reset();
+    void destroy();
+};
+
+struct ProfScope {
+    Profiler *p; hipStream_t s; int idx;
+    ProfScope(Profiler *p_, hipStream_t s_, int cls, double w) : p(p_), s(s_), idx(-1) {
+        if (p && p->on) idx = p->begin(s, cls, w);
+    }
+    ~ProfScope() { if (idx >= 0) p->end(s, idx); }
+};
+
+// ---- the fitted model held in HBM ------------------------------------------------------------
+struct gpx_handle {
+    int device = 0;
+    int64_t n = 0, npad = 0, nblk = 0;
+    int d = 0;
+    double v = 0, vt = 0, jitter = 0;
+    double theta[GPX_MAX_D + 2];
+    double w[GPX_MAX_D];
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+
+    double *x = nullptr;        // [n, d] raw inputs
+    double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
+    double *sw = nullptr;       // [d] sqrt(w) on device
+    double *wdev = nullptr;     // [d] w on device
+    double *L = nullptr;        // [npad, npad] lower Cholesky factor (blocks above the diagonal unused)
+    double *Dinv = nullptr;     // [nblk, 128, 128] inverses of the diagonal blocks of L
+    double *diagL = nullptr;    // [npad]
+    double *t = nullptr;        // [npad] centred targets (zero padded)
+    double *y = nullptr;        // [npad] L^-1 t
+    double *alpha = nullptr;    // [npad] K^-1 t
+    double *Kinv = nullptr;     // [npad, npad] lazily materialised
+    int *info_dev = nullptr;
+    double logdet = 0;
+    bool have_logdet = false;
+
+    // scratch
+    double *Z = nullptr;        // predict / inverse workspace [zrows, npad]
+    int64_t zrows = 0;
+    double *small = nullptr;    // small device scratch (reductions, propagate vectors)
+    int64_t small_elems = 0;
+
+    // propagate cache (keyed on u)
+    bool have_u = false;
+    double u[GPX_MAX_D];
+    double *V = nullptr;        // [ncolV, npad] column-major block of C, J_k, hh_k, tr
+    double *KV = nullptr;       // [ncolV, npad] Kinv * V
+    Profiler prof;
+};
+
+// ---- kernels / host launchers implemented across the .hip files -------------------------------
+int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, int d, double v, double add_diag,
+                int lower_only, int pad_mode, double *out, int64_t ld, int64_t rows_pad, int64_t cols_pad,
+                hipStream_t s, Profiler *prof);
+int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
+int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
+                   hipStream_t s, Profiler *prof);
+int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
+                      hipStream_t s, Profiler *prof);
+
+// recursive blocked algorithms (chol.hip)
+int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
+                hipStream_t s, Profiler *prof);
+// Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
+int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
+                  int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
+int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
+                 double *scratch, hipStream_t s, Profiler *prof);
+int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,
+                  double *scratch, hipStream_t s, Profiler *prof);
+int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
+int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
+                          double *mean, double *var, hipStream_t s, Profiler *prof);
+int launch_set_identity(double *Z, int64_t ld, int64_t n, hipStream_t s);
+int launch_symmetrize_lower(double *A, int64_t ld, int64_t n, hipStream_t s);
+
+// propagate.hip
+int propagate_build_V(gpx_handle *h, const double *u_host);

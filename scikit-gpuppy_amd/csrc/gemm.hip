@@ -1,0 +1,199 @@
+// gemm.hip -- fp64 MFMA GEMM  C = alpha * A B^T + beta * C  for gfx950 (v_mfma_f64_16x16x4_f64).
+//
+// The one dense contraction of the path: every flop of the blocked Cholesky (SYRK trailing updates,
+// panel TRSM against inverted diagonal blocks) and of the multi-RHS triangular solve behind
+// estimate_many (the reference's two N^2 M GEMMs at skgpuppy/GaussianProcess.py:77-78 and its LU
+// inverse at skgpuppy/Covariance.py:179) runs through this kernel.  Both operands are K-contiguous
+// row-major panels ("NT"), which is what a row-major lower-triangular factor gives for L L^T-type
+// products.
+//
+// Tiling: 128x128 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles of 16x16 (16
+// independent accumulators, 128 VGPRs).  k is staged 16 deep through double-buffered LDS with one
+// barrier per stage; global loads are 16 B/lane with 8 lanes covering one 128-B row segment; LDS
+// rows are padded to 18 doubles so the per-lane ds_read_b64 fragment reads (lane l -> row l&15,
+// k l>>4) are bank-conflict free.  LDS 72 KiB/block -> 2 blocks per CU.
+#include "common.h"
+
+constexpr int BM = 128, BN = 128;
+
+template <bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda,
+                                                            const double *B, long ldb, double *C,
+                                                            long ldc, int K, double alpha, double beta)
+{
+    __shared__ __attribute__((aligned(16))) double As[2][BM * GEMM_LDS_S];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BN * GEMM_LDS_S];
+
+    const int bx = blockIdx.x, by = blockIdx.y;   // bx: column tile, by: row tile
+    if (LOWER && bx > by) return;
+
+    const int t = threadIdx.x;
+    const int lr = t >> 3, lc = t & 7;            // staging: row lr (+32 i), 16-byte column chunk lc
+    const int wave = t >> 6, lane = t & 63;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const double *Ag = A + ((long)by * BM + lr) * lda + 2 * lc;
+    const double *Bg = B + ((long)bx * BN + lr) * ldb + 2 * lc;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    v2d ga[4], gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        ga[i] = *reinterpret_cast<const v2d *>(Ag + (long)(32 * i) * lda);
+        gb[i] = *reinterpret_cast<const v2d *>(Bg + (long)(32 * i) * ldb);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<v2d *>(&As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = ga[i];
+        *reinterpret_cast<v2d *>(&Bs[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = gb[i];
+    }
+    __syncthreads();
+
+    const int nk = K / GEMM_BK;
+    const int a_off = (wr * 64 + fr) * GEMM_LDS_S + fq;
+    const int b_off = (wc * 64 + fr) * GEMM_LDS_S + fq;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const double *Ak = Ag + (long)(kt + 1) * GEMM_BK;
+            const double *Bk = Bg + (long)(kt + 1) * GEMM_BK;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ga[i] = *reinterpret_cast<const v2d *>(Ak + (long)(32 * i) * lda);
+                gb[i] = *reinterpret_cast<const v2d *>(Bk + (long)(32 * i) * ldb);
+            }
+        }
+        const double *as = &As[cur][a_off];
+        const double *bs = &Bs[cur][b_off];
+#pragma unroll
+        for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
+            double af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = as[i * 16 * GEMM_LDS_S + kk * 4];
+                bf[i] = bs[i * 16 * GEMM_LDS_S + kk * 4];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            const int nxt = cur ^ 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<v2d *>(&As[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = ga[i];
+                *reinterpret_cast<v2d *>(&Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = gb[i];
+            }
+        }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register r of tile (i,j) is C[row = fq + 4r][col = fr] of that 16x16 tile
+    double *Cw = C + ((long)by * BM + wr * 64 + fq) * ldc + (long)bx * BN + wc * 64 + fr;
+    if (beta == 0.0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *p = &Cw[(long)(i * 16 + 4 * r) * ldc + j * 16];
+                    *p = fma(alpha, acc[i][j][r], beta * (*p));
+                }
+    }
+}
+
+int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof)
+{
+    if (M % BM || N % BN || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
+        ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
+        gpx_set_error("launch_gemm_nt: shape/alignment not supported (M=%ld N=%ld K=%ld lda=%ld ldb=%ld)", (long)M,
+                      (long)N, (long)K, (long)lda, (long)ldb);
+        return GPX_ERR_BAD_ARG;
+    }
+    if (M == 0 || N == 0) return 0;
+    if (lower_only && M != N) {
+        gpx_set_error("launch_gemm_nt: lower_only needs a square C");
+        return GPX_ERR_BAD_ARG;
+    }
+    dim3 grid((unsigned)(N / BN), (unsigned)(M / BM));
+    double tiles = lower_only ? 0.5 * (double)(M / BM) * (double)(M / BM + 1) : (double)(M / BM) * (double)(N / BN);
+    ProfScope ps(prof, s, GPX_K_GEMM, tiles * 2.0 * BM * BN * (double)K);
+    if (lower_only)
+        hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc,
+                           (int)K, alpha, beta);
+    else
+        hipLaunchKernelGGL(gemm_nt_f64_kernel<false>, grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc,
+                           (int)K, alpha, beta);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- micro-benchmark: issue rate of v_mfma_f64_16x16x4_f64 (roofline denominator check) ----------
+__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double *out, int iters)
+{
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int gpx_bench_mfma_f64(int iters, double *tflops)
+{
+    if (!tflops || iters <= 0) return GPX_ERR_BAD_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        gpx_set_error("no HIP device");
+        return GPX_ERR_NO_DEVICE;
+    }
+    const int blocks = 256 * 8, threads = 256;
+    double *out = nullptr;
+    GPX_HIP(hipMalloc(&out, sizeof(double) * blocks * threads));
+    hipEvent_t e0, e1;
+    GPX_HIP(hipEventCreate(&e0));
+    GPX_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(threads), 0, 0, out, 16);   // warm-up
+    GPX_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(threads), 0, 0, out, iters);
+    GPX_HIP(hipEventRecord(e1, 0));
+    GPX_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    double flops = (double)blocks * (threads / 64) * (double)iters * 8.0 * (16.0 * 16.0 * 4.0 * 2.0);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    return 0;
+}
+
+extern "C" int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
+                               int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream)
+{
+    return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, lower_only, (hipStream_t)stream, nullptr);
+}

@@ -1,0 +1,298 @@
+// propagate.hip -- Girard uncertainty propagation (Approx and Exact) on the fitted model, gfx950.
+//
+// Device equivalents of the reference's only native component, skgpuppy/UncertaintyPropagation2.pyx
+// (Cython twins of skgpuppy/UncertaintyPropagation.py:246-630), loops K1..K8 of SURVEY.md 2a:
+//   K8  C_ux / J_ux / H_ux build (3N Python calls in the reference)      -> approx_build_kernel / cjh_kernel
+//   K2..K6  sum_ij Kinv_ij a_i b_j quadratic forms (serial N^2 passes)     -> ONE pass Kinv x [C, J_1..J_d]
+//           (the forms against tr / H_hh reuse Kinv C by symmetry)        +  row dot products
+//   K7  exact mean  sum_i beta_i l_i                                       -> exact_build_kernel + dot
+//   K1  exact variance double sum over L_ij = C_i C_j nc exp(1/2 z^T Lambda^-1 z)
+//       -> exact_sum_kernel: each thread owns a column j (coalesced Kinv reads), a workgroup owns 16
+//          rows; the d^2 inner loop is factorised as exp(e_i + e_j + b_i . a_j), b_i = Lambda^-1 a_i / 4.
+#include "common.h"
+
+__device__ __forceinline__ double wave_sum_p(double s)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Approx: per-row quantities for a given u.   VM rows: 0 = C, 1..d = J_k.   AUX rows: 1..d = H_kk
+// c_i = v exp(-1/2 sum w_k delta_k^2), delta = x_i - u          (Covariance.py:660-689)
+// C_i = c_i + vt iff x_i == u elementwise                        (Covariance.py:440-451)
+// J_i[k] = -delta_k w_k c_i ; H_i[k][k] = ((w_k delta_k)^2 - w_k) c_i
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void approx_build_kernel(const double *__restrict__ x, long n, long npad, int d,
+                                                          const double *__restrict__ u, const double *__restrict__ w,
+                                                          double v, double vt, double *__restrict__ VM,
+                                                          double *__restrict__ AUX, double *__restrict__ cplain)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) {
+        for (int k = 0; k <= d; ++k) VM[(long)k * npad + i] = 0.0;
+        for (int k = 0; k <= d; ++k) AUX[(long)k * npad + i] = 0.0;
+        cplain[i] = 0.0;
+        return;
+    }
+    double q = 0.0;
+    bool same = true;
+    for (int k = 0; k < d; ++k) {
+        const double xv = x[i * d + k], uv = u[k];
+        const double dl = xv - uv;
+        same = same && (xv == uv);
+        q = fma(w[k] * dl, dl, q);
+    }
+    const double c = v * exp(-0.5 * q);
+    cplain[i] = c;
+    VM[i] = same ? c + vt : c;
+    for (int k = 0; k < d; ++k) {
+        const double dl = x[i * d + k] - u[k];
+        const double wd = w[k] * dl;
+        VM[(long)(k + 1) * npad + i] = -dl * w[k] * c;
+        AUX[(long)(k + 1) * npad + i] = (wd * wd - w[k]) * c;
+    }
+}
+
+// tr_i = tr(H_i Sigma) = c_i ( (w delta)^T Sigma (w delta) - sum_k w_k Sigma_kk )   -> AUX row 0
+// (tracedot(H, Sigma), UncertaintyPropagation.py:464 / Covariance.py:101-109; full Sigma allowed)
+__global__ __launch_bounds__(256) void trace_kernel(const double *__restrict__ x, long n, long npad, int d,
+                                                   const double *__restrict__ u, const double *__restrict__ w,
+                                                   const double *__restrict__ Sigma, const double *__restrict__ cplain,
+                                                   double *__restrict__ tr)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) { tr[i] = 0.0; return; }
+    double s = 0.0, wdiag = 0.0;
+    for (int a = 0; a < d; ++a) {
+        const double wa = w[a] * (x[i * d + a] - u[a]);
+        double row = 0.0;
+        for (int b = 0; b < d; ++b) row = fma(Sigma[a * d + b], w[b] * (x[i * d + b] - u[b]), row);
+        s = fma(wa, row, s);
+        wdiag = fma(w[a], Sigma[a * d + a], wdiag);
+    }
+    tr[i] = cplain[i] * (s - wdiag);
+}
+
+// out[p] = sum_i P_p[i] Q_p[i], one workgroup per pair, fixed summation order (deterministic)
+struct DotPairs { const double *p[80]; const double *q[80]; };
+__global__ __launch_bounds__(256) void dot_pairs_kernel(DotPairs pairs, long n, double *__restrict__ out)
+{
+    __shared__ double ws[4];
+    const double *P = pairs.p[blockIdx.x], *Q = pairs.q[blockIdx.x];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) s = fma(P[i], Q[i], s);
+    s = wave_sum_p(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev,
+                     hipStream_t s)
+{
+    size_t done = 0;
+    while (done < pr.size()) {
+        DotPairs dp;
+        size_t cnt = std::min<size_t>(80, pr.size() - done);
+        for (size_t i = 0; i < cnt; ++i) { dp.p[i] = pr[done + i].first; dp.q[i] = pr[done + i].second; }
+        hipLaunchKernelGGL(dot_pairs_kernel, dim3((unsigned)cnt), dim3(256), 0, s, dp, n, out_dev + done);
+        done += cnt;
+    }
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// full C / J / H arrays for the host-side attributes C_ux, J_ux, H_ux
+__global__ __launch_bounds__(256) void cjh_kernel(const double *__restrict__ x, long n, int d,
+                                                 const double *__restrict__ u, const double *__restrict__ w, double v,
+                                                 double vt, double *C, double *J, double *H)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double q = 0.0;
+    bool same = true;
+    for (int k = 0; k < d; ++k) {
+        const double xv = x[i * d + k], uv = u[k];
+        const double dl = xv - uv;
+        same = same && (xv == uv);
+        q = fma(w[k] * dl, dl, q);
+    }
+    const double c = v * exp(-0.5 * q);
+    if (C) C[i] = same ? c + vt : c;
+    if (J)
+        for (int k = 0; k < d; ++k) J[i * d + k] = -(x[i * d + k] - u[k]) * w[k] * c;
+    if (H)
+        for (int a = 0; a < d; ++a) {
+            const double wa = w[a] * (x[i * d + a] - u[a]);
+            for (int b = 0; b < d; ++b) {
+                const double wb = w[b] * (x[i * d + b] - u[b]);
+                H[(i * d + a) * d + b] = (wa * wb - (a == b ? w[a] : 0.0)) * c;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Exact: per-row quantities.  a_i = u - x_i.
+//   aT[k][i] = a_ik                       (k-major so the pair kernel loads it coalesced)
+//   bT[k][i] = 1/4 (Ls a_i)_k             Ls = symmetric part of Lambda^-1 (UP.py:292-303)
+//   e_i  = -1/2 a_i^T W^-1 a_i + 1/8 a_i^T Ls a_i          (log of C_i exp(1/8 ...), without v and quirk)
+//   F_i  = v f_i,  f_i = (v+vt)/v when x_i == u else 1      (the +vt quirk folded into a factor)
+//   lm_i = C_i nc1 exp(1/2 a_i^T Delta^-1 a_i), Delta^-1 = diag(w_k - w_k/(1+w_k s_k))   (UP.py:247-290)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void exact_build_kernel(const double *__restrict__ x, long n, long npad, int d,
+                                                         const double *__restrict__ u, const double *__restrict__ w,
+                                                         const double *__restrict__ Ls, const double *__restrict__ dinv_diag,
+                                                         double v, double vt, double nc1, double *__restrict__ aT,
+                                                         double *__restrict__ bT, double *__restrict__ e,
+                                                         double *__restrict__ F, double *__restrict__ lm)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) {
+        for (int k = 0; k < d; ++k) { aT[(long)k * npad + i] = 0.0; bT[(long)k * npad + i] = 0.0; }
+        e[i] = 0.0; F[i] = 0.0; lm[i] = 0.0;     // F = 0 removes padded rows/columns from every sum
+        return;
+    }
+    double qw = 0.0, qd = 0.0, ql = 0.0;
+    bool same = true;
+    for (int k = 0; k < d; ++k) {
+        const double xv = x[i * d + k], uv = u[k];
+        same = same && (xv == uv);
+        const double ak = uv - xv;
+        aT[(long)k * npad + i] = ak;
+        qw = fma(w[k] * ak, ak, qw);
+        qd = fma(dinv_diag[k] * ak, ak, qd);
+    }
+    for (int k = 0; k < d; ++k) {
+        double row = 0.0;
+        for (int b = 0; b < d; ++b) row = fma(Ls[k * d + b], u[b] - x[i * d + b], row);
+        bT[(long)k * npad + i] = 0.25 * row;
+        ql = fma(u[k] - x[i * d + k], row, ql);
+    }
+    e[i] = -0.5 * qw + 0.125 * ql;
+    const double c = v * exp(-0.5 * qw);
+    const double Ci = same ? c + vt : c;
+    F[i] = same ? (v + vt) : v;
+    lm[i] = Ci * nc1 * exp(0.5 * qd);
+}
+
+// S = sum_ij (Kinv_ij - beta_i beta_j) F_i F_j exp(e_i + e_j + b_i . a_j); the caller multiplies by nc2.
+// Workgroup = 16 rows x all columns; thread = column j (stride 256).  partial[blockIdx.x] = block sum.
+template <int DMAX>
+__global__ __launch_bounds__(256) void exact_sum_kernel(const double *__restrict__ Kinv, long ld, long npad, int d,
+                                                       const double *__restrict__ beta, const double *__restrict__ aT,
+                                                       const double *__restrict__ bT, const double *__restrict__ e,
+                                                       const double *__restrict__ F, double *__restrict__ partial)
+{
+    __shared__ double bs[16][DMAX];      // b_i for the block's 16 rows (broadcast reads)
+    __shared__ double rs[16][3];         // e_i, F_i, beta_i
+    __shared__ double ws[4];
+    const int t = threadIdx.x;
+    const long i0 = (long)blockIdx.x * 16;
+    for (int q = t; q < 16 * d; q += 256) { const int r = q / d, k = q - r * d; bs[r][k] = bT[(long)k * npad + i0 + r]; }
+    if (t < 16) { rs[t][0] = e[i0 + t]; rs[t][1] = F[i0 + t]; rs[t][2] = beta[i0 + t]; }
+    __syncthreads();
+
+    double acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+
+    for (long j = t; j < npad; j += 256) {
+        double aj[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) aj[k] = (k < d) ? aT[(long)k * npad + j] : 0.0;
+        const double ej = e[j], Fj = F[j], bj = beta[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double dot = rs[r][0] + ej;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k)
+                if (k < d) dot = fma(bs[r][k], aj[k], dot);
+            const double kij = Kinv[(i0 + r) * ld + j];
+            acc[r] = fma((kij - rs[r][2] * bj) * Fj, exp(dot), acc[r]);
+        }
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s = fma(acc[r], rs[r][1], s);
+    s = wave_sum_p(s);
+    if ((t & 63) == 0) ws[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_vector_kernel(const double *__restrict__ p, long n, double *out)
+{
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) s += p[i];
+    s = wave_sum_p(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
+                     const double *bT, const double *e, const double *F, double *partial, double *out_dev,
+                     hipStream_t s, Profiler *prof)
+{
+    const unsigned nblk = (unsigned)(npad / 16);
+    {
+        // algorithmic flops: N^2 (2d + ~25) + N^2 exp
+        ProfScope ps(prof, s, GPX_K_EXACT, (double)npad * (double)npad * (2.0 * d + 25.0));
+        if (d <= 4)
+            hipLaunchKernelGGL(exact_sum_kernel<4>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        else if (d <= 8)
+            hipLaunchKernelGGL(exact_sum_kernel<8>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        else if (d <= 16)
+            hipLaunchKernelGGL(exact_sum_kernel<16>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        else if (d <= 32)
+            hipLaunchKernelGGL(exact_sum_kernel<32>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        else
+            hipLaunchKernelGGL(exact_sum_kernel<64>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+    }
+    hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, (long)nblk, out_dev);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_approx_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
+                        double v, double vt, double *VM, double *AUX, double *cplain, hipStream_t s)
+{
+    hipLaunchKernelGGL(approx_build_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, x, (long)n, (long)npad,
+                       d, u_dev, w_dev, v, vt, VM, AUX, cplain);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_trace(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
+                 const double *Sigma_dev, const double *cplain, double *tr, hipStream_t s)
+{
+    hipLaunchKernelGGL(trace_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, x, (long)n, (long)npad, d,
+                       u_dev, w_dev, Sigma_dev, cplain, tr);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_cjh(const double *x, int64_t n, int d, const double *u_dev, const double *w_dev, double v, double vt,
+               double *C, double *J, double *H, hipStream_t s)
+{
+    hipLaunchKernelGGL(cjh_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, (long)n, d, u_dev, w_dev, v, vt,
+                       C, J, H);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_exact_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
+                       const double *Ls_dev, const double *dinv_diag_dev, double v, double vt, double nc1, double *aT,
+                       double *bT, double *e, double *F, double *lm, hipStream_t s)
+{
+    hipLaunchKernelGGL(exact_build_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, x, (long)n, (long)npad,
+                       d, u_dev, w_dev, Ls_dev, dinv_diag_dev, v, vt, nc1, aT, bT, e, F, lm);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,134 @@
+"""Covariance operator interface -- host-side mirror of skgpuppy/Covariance.py for the hot path.
+
+`Covariance` is the reference's operator interface (skgpuppy/Covariance.py:111-359); only
+`GaussianCovariance` (:435-689) is on the accelerated path.  Matrix-sized work (cov_matrix_ij,
+cov_matrix, inv_cov_matrix) is done by libgpx on the GPU; the scalar accessors (__call__, get_theta,
+get_Jacobian, get_Hessian: O(d^2) per call) are plain host arithmetic exactly as the reference defines
+them -- their batched forms are gpx_cjh / the fused device kernels.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _gpx
+
+
+def tracedot(A, B):
+    """trace(dot(A, B))  (skgpuppy/Covariance.py:101-109)."""
+    return np.dot(np.ravel(np.asarray(A).T), np.ravel(B))
+
+
+class Covariance(object):
+    """Superclass for all covariance functions (skgpuppy/Covariance.py:111-359): the interface
+    GaussianProcess talks to."""
+
+    def __init__(self):
+        pass
+
+    def __call__(self, xi, xj, theta):
+        raise NotImplementedError
+
+    def get_theta(self, x, t):
+        raise NotImplementedError
+
+    def cov_matrix_ij(self, xi, xj, theta):
+        raise NotImplementedError
+
+    def cov_matrix(self, x, theta):
+        return self.cov_matrix_ij(x, x, theta)
+
+    def inv_cov_matrix(self, x, theta, cov_matrix=None):
+        raise NotImplementedError
+
+    def get_Hessian(self, u, xi, theta):
+        raise NotImplementedError
+
+    def get_Jacobian(self, u, xi, theta):
+        raise NotImplementedError
+
+
+def _theta(theta, d):
+    th = _gpx.f64(theta)
+    if th.ndim != 1 or th.shape[0] != d + 2:
+        raise ValueError("theta must have 2 + d = %d entries, got shape %r" % (d + 2, th.shape))
+    return th
+
+
+class GaussianCovariance(Covariance):
+    """ARD squared-exponential kernel, theta = (log v, log vt, log w_1..w_d)
+    (skgpuppy/Covariance.py:435-689)."""
+
+    def __call__(self, xi, xj, theta):
+        # scalar kernel incl. the "+vt iff xi == xj elementwise" hack (Covariance.py:440-451)
+        xi = np.asarray(xi)
+        xj = np.asarray(xj)
+        with np.errstate(divide="ignore"):
+            v = np.exp(theta[0])
+            vt = np.exp(theta[1])
+            w = np.exp(np.asarray(theta[2:], dtype=float))
+        diff = xi - xj
+        return v * np.exp(-0.5 * np.dot(diff, w * diff)) + (vt if (xi == xj).all() else 0)
+
+    def get_theta(self, x, t):
+        # initial guess for the hyper-parameter search (Covariance.py:453-459)
+        n, d = np.shape(x)
+        theta = np.ones(2 + d)
+        theta[0] = np.log(np.var(t)) if t is not None else 1
+        theta[1] = np.log(np.var(t) / 4) if t is not None else 1
+        theta[2:] = -2 * np.log((np.max(x, 0) - np.min(x, 0)) / 2.0)
+        return theta
+
+    def _gram(self, xi, xj, theta, add_diag):
+        a = _gpx.f64(xi)
+        b = a if xj is xi else _gpx.f64(xj)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+            raise ValueError("inputs must be (n, d) arrays with equal d")
+        th = _theta(theta, a.shape[1])
+        K = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+        if K.size:
+            st = _gpx.lib.gpx_gram(_gpx.ptr(a), a.shape[0], _gpx.ptr(b), b.shape[0], a.shape[1], _gpx.ptr(th),
+                                   float(add_diag), _gpx.ptr(K))
+            _gpx.check(st, "gpx_gram")
+        return K
+
+    def cov_matrix_ij(self, xi, xj, theta):
+        """N1 x N2 cross-covariance without the noise term (Covariance.py:466-483) -- HIP Gram kernel."""
+        return self._gram(xi, xj, theta, 0.0)
+
+    def cov_matrix(self, x, theta):
+        """cov_matrix_ij(x, x) + vt I (Covariance.py:461-464); the diagonal add is fused in the kernel."""
+        with np.errstate(divide="ignore"):
+            vt = float(np.exp(theta[1]))
+        return self._gram(x, x, theta, vt)
+
+    def inv_cov_matrix(self, x, theta, cov_matrix=None):
+        """K^-1 (Covariance.py:167-187).  The reference LU-inverts; here K is Cholesky-factored on the GPU
+        (with the reference's +1e-5 I retry on a non-PD pivot) and K^-1 = L^-T L^-1."""
+        if cov_matrix is not None:
+            raise NotImplementedError("inverting a caller-supplied matrix is outside the accelerated path")
+        from .GaussianProcess import _DeviceModel
+        xa = _gpx.f64(x)
+        model = _DeviceModel(xa, np.zeros(xa.shape[0]), _theta(theta, xa.shape[1]))
+        try:
+            return model.kinv()
+        finally:
+            model.close()
+
+    def get_Hessian(self, u, xi, theta):
+        # (Covariance.py:660-674)
+        with np.errstate(divide="ignore"):
+            v = np.exp(theta[0])
+            w = np.exp(np.asarray(theta[2:], dtype=float))
+        diff = np.asarray(xi, dtype=float) - np.asarray(u, dtype=float)
+        e = v * np.exp(-0.5 * np.dot(diff, w * diff))
+        wd = diff * w
+        return (np.outer(wd, wd) - np.diag(w)) * e
+
+    def get_Jacobian(self, u, xi, theta):
+        # (Covariance.py:676-689): -(xi-u) w c as a (d,1) column
+        with np.errstate(divide="ignore"):
+            v = np.exp(theta[0])
+            w = np.exp(np.asarray(theta[2:], dtype=float))
+        diff = np.asarray(xi, dtype=float) - np.asarray(u, dtype=float)
+        e = v * np.exp(-0.5 * np.dot(diff, w * diff))
+        return np.atleast_2d(-diff * w * e).T

@@ -1,0 +1,181 @@
+"""GaussianProcess -- host-side mirror of skgpuppy/GaussianProcess.py over the libgpx handle.
+
+The fitted model (Cholesky factor of K, inverted diagonal blocks, alpha, lazily K^-1) lives in HBM
+behind a gpx_handle; this object keeps the reference's public attributes (x, n, d, meant, t, cov,
+theta_min, Kinv) and stays picklable (the handle is rebuilt lazily after unpickling, cf. the
+reference's pickle test skgpuppy/tests/tests.py:626-659).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _gpx
+from .Covariance import GaussianCovariance
+
+
+class _DeviceModel(object):
+    """Owner of one gpx_handle (single stream, single owner)."""
+
+    def __init__(self, x, t_centered, theta, stream=None):
+        self.n, self.d = x.shape
+        self._h = ctypes.c_void_p()
+        st = _gpx.lib.gpx_fit(_gpx.ptr(x), _gpx.ptr(t_centered), self.n, self.d, _gpx.ptr(theta),
+                              ctypes.c_void_p(stream or 0), ctypes.byref(self._h))
+        _gpx.check(st, "gpx_fit")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("device model already released")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _gpx.lib.gpx_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def predict(self, xs):
+        m = xs.shape[0]
+        mean = np.empty(m)
+        var = np.empty(m)
+        _gpx.check(_gpx.lib.gpx_predict(self.handle, _gpx.ptr(xs), m, _gpx.ptr(mean), _gpx.ptr(var)), "gpx_predict")
+        return mean, var
+
+    def alpha(self):
+        out = np.empty(self.n)
+        _gpx.check(_gpx.lib.gpx_alpha(self.handle, _gpx.ptr(out)), "gpx_alpha")
+        return out
+
+    def kinv(self):
+        out = np.empty((self.n, self.n))
+        _gpx.check(_gpx.lib.gpx_kinv(self.handle, _gpx.ptr(out)), "gpx_kinv")
+        return out
+
+    def chol(self):
+        out = np.empty((self.n, self.n))
+        _gpx.check(_gpx.lib.gpx_chol(self.handle, _gpx.ptr(out)), "gpx_chol")
+        return out
+
+    def logdet(self):
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_logdet(self.handle, ctypes.byref(v)), "gpx_logdet")
+        return v.value
+
+    def jitter(self):
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_jitter_used(self.handle, ctypes.byref(v)), "gpx_jitter_used")
+        return v.value
+
+
+class GaussianProcess(object):
+    """GP regression object (skgpuppy/GaussianProcess.py:11-191)."""
+
+    def __init__(self, x, t, cov, theta_min=None):
+        # (GaussianProcess.py:19-41): x stored as given, targets centred, Kinv <- factorisation on the GPU
+        self.x = x
+        self.n, self.d = np.shape(x)
+        self.meant = np.mean(t)
+        self.t = t - self.meant
+        self.cov = cov
+        if theta_min is not None:
+            self.theta_min = theta_min
+        else:
+            self.theta_min = self.cov.ml_estimate(self.x, self.t)
+        self._model = None
+        self._Kinv = None
+        self._fit()
+
+    # ---- device model management -----------------------------------------------------------
+    def _fit(self):
+        if not isinstance(self.cov, GaussianCovariance):
+            raise TypeError("only GaussianCovariance is on the accelerated path")
+        self._model = _DeviceModel(_gpx.f64(self.x), _gpx.f64(self.t), _gpx.f64(self.theta_min))
+
+    def _dev(self):
+        if self._model is None:
+            self._fit()
+        return self._model
+
+    @property
+    def Kinv(self):
+        """K^-1 as a NumPy array, materialised on first access (the reference stores it eagerly,
+        GaussianProcess.py:41)."""
+        if self._Kinv is None:
+            self._Kinv = self._dev().kinv()
+        return self._Kinv
+
+    @Kinv.setter
+    def Kinv(self, value):
+        self._Kinv = value
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_model"] = None          # raw device handles never enter the pickle
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._model = None
+
+    # ---- reference API -------------------------------------------------------------------------
+    @staticmethod
+    def get_realisation(x, cov, theta):
+        # (GaussianProcess.py:44-57)
+        n, d = np.shape(x)
+        K = cov.cov_matrix(x, theta)
+        return np.random.multivariate_normal(np.zeros(n), K)
+
+    def __call__(self, x_star):
+        return self.estimate(x_star)
+
+    def estimate_many(self, x_stars):
+        """(GaussianProcess.py:68-80): mean + meant and diag(k - kv Kinv kv^T) for M query points --
+        cross-covariance, multi-RHS triangular solve and row reductions on the GPU, no M x M matrix."""
+        xs = _gpx.f64(np.array(x_stars))
+        if xs.ndim != 2 or xs.shape[1] != self.d:
+            raise ValueError("x_stars must be (m, %d)" % self.d)
+        mean, var = self._dev().predict(xs)
+        return mean + self.meant, var
+
+    def estimate(self, x_star):
+        """(GaussianProcess.py:94-111): single-point twin of estimate_many."""
+        xs = _gpx.f64(np.atleast_2d(np.array(x_star)))
+        mean, var = self._dev().predict(xs)
+        return mean[0] + self.meant, var[0]
+
+    def _get_beta(self):
+        # beta = K^-1 t (GaussianProcess.py:114-119)
+        return self._dev().alpha()
+
+    def _get_W_inv(self):
+        w = np.exp(self.theta_min[2:self.d + 2])
+        return np.diag(w)
+
+    def _get_v(self):
+        return np.exp(self.theta_min[0])
+
+    def _get_vt(self):
+        return np.exp(self.theta_min[1])
+
+    def _covariance(self, xi, xj, v=None, w=None):
+        # (GaussianProcess.py:133-149) incl. the in-place theta mutation when v / w are passed
+        theta = self.theta_min
+        if v is not None:
+            theta[0] = np.log(v)
+        if w is not None:
+            theta[2:] = np.log(w)
+        return self.cov(xi, xj, theta)
+
+    def _inv_cov_matrix(self):
+        return self.Kinv
+
+    def _get_mean_t(self):
+        return self.meant
+
+    def _get_Hessian(self, u, xi):
+        return self.cov.get_Hessian(u, xi, self.theta_min)
+
+    def _get_Jacobian(self, u, xi):
+        return self.cov.get_Jacobian(u, xi, self.theta_min)

@@ -1,0 +1,96 @@
+"""ctypes binding of libgpx (include/gpx.h) -- the thin C-ABI under the skgpuppy-compatible classes.
+
+There is no CPU fallback: if libgpx.so is missing the import fails, and if no gfx950 device is visible
+every compute call raises.  Status codes follow include/gpx.h: >0 LAPACK-style info ->
+numpy.linalg.LinAlgError (what the reference surfaces, skgpuppy/Covariance.py:213,309), GPX_ERR_BAD_ARG
+-> ValueError, anything else -> RuntimeError with gpx_last_error().
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpx.so")
+
+GPX_ERR_BAD_ARG, GPX_ERR_HIP, GPX_ERR_NO_DEVICE, GPX_ERR_STATE = -1, -2, -3, -4
+K_GRAM, K_GEMM, K_POTRF_LEAF, K_TRSV, K_REDUCE, K_QUAD, K_EXACT = range(7)
+KERNEL_CLASS_NAMES = ["gram", "gemm_f64_mfma", "potrf_leaf", "trsv", "predict_reduce", "approx_quad", "exact_sum"]
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libgpx.so not found at %s: build it with `make -C scikit-gpuppy_amd/csrc` (or "
+        "`python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_dp = ctypes.c_void_p          # double* that may be a host or a device pointer
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_dbl = ctypes.c_double
+_hp = ctypes.c_void_p          # gpx_handle*
+
+# name -> (restype, argtypes): every symbol include/gpx.h declares
+SIGNATURES = {
+    "gpx_abi_version": (_int, []),
+    "gpx_last_error": (ctypes.c_char_p, []),
+    "gpx_device_count": (_int, []),
+    "gpx_set_device": (_int, [_int]),
+    "gpx_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _dp]),
+    "gpx_fit": (_int, [_dp, _dp, _i64, _int, _dp, ctypes.c_void_p, ctypes.POINTER(_hp)]),
+    "gpx_free": (None, [_hp]),
+    "gpx_n": (_int, [_hp, ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
+    "gpx_jitter_used": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_logdet": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
+    "gpx_alpha": (_int, [_hp, _dp]),
+    "gpx_kinv": (_int, [_hp, _dp]),
+    "gpx_chol": (_int, [_hp, _dp]),
+    "gpx_cjh": (_int, [_hp, _dp, _dp, _dp, _dp]),
+    "gpx_propagate_approx": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 4),
+    "gpx_propagate_dvh": (_int, [_hp, _dp, _dp]),
+    "gpx_propagate_exact": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "gpx_exact_mean": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl)]),
+    "gpx_profile_enable": (_int, [_hp, _int]),
+    "gpx_profile_reset": (_int, [_hp]),
+    "gpx_profile_read": (_int, [_hp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "gpx_bench_mfma_f64": (_int, [_int, ctypes.POINTER(_dbl)]),
+    "gpx_bench_hbm": (_int, [_i64, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "gpx_dev_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
+    "gpx_dev_gemm_nt": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, _int, ctypes.c_void_p]),
+    "gpx_dev_potrf_leaf": (_int, [_dp, _i64, _dp, _dp, ctypes.c_void_p, _int, ctypes.c_void_p]),
+}
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)          # AttributeError here = header and library out of sync
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def last_error():
+    msg = lib.gpx_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status, what):
+    if status == 0:
+        return
+    msg = "%s failed (status %d): %s" % (what, status, last_error())
+    if status > 0:
+        raise np.linalg.LinAlgError(msg)
+    if status == GPX_ERR_BAD_ARG:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def f64(a):
+    """C-contiguous float64 view/copy of array-like `a` (the reference accepts int arrays and lists)."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    """void* of a NumPy array (host) -- keep `a` alive for the duration of the call."""
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def device_count():
+    return int(lib.gpx_device_count())

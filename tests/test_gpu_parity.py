@@ -1,0 +1,381 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against
+  (1) golden vectors generated from the genuine reference (tests/golden, tools/gen_golden.py),
+  (2) the CPU oracle on the same seeded inputs, and
+  (3) size-independent properties at the BASELINE sizes.
+Tolerances follow SURVEY.md 8a: Gram rel 1e-13; estimate_many rtol 1e-6 / atol 1e-9 v; propagated
+means atol 1e-9, variances ABSOLUTE atol 1e-8 v (differences of O(v) terms); METIS (cond 1.6e7) 10x.
+"""
+import ctypes
+import pickle
+
+import numpy as np
+import pytest
+
+from conftest import GP_CASES, load_golden, torch
+
+import skgpuppy_amd as sk
+from skgpuppy_amd import _gpx
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# building blocks on device pointers
+# ------------------------------------------------------------------------------------------------
+def test_device_is_gfx950_and_library_loaded():
+    assert _gpx.device_count() >= 1
+    tf = ctypes.c_double()
+    _gpx.check(_gpx.lib.gpx_bench_mfma_f64(2000, ctypes.byref(tf)), "mfma bench")
+    assert tf.value > 10.0          # fp64 MFMA is alive (vendor peak 78.6 TFLOP/s)
+
+
+@pytest.mark.parametrize("M,N,K,lower", [(128, 128, 16, 0), (256, 128, 48, 0), (384, 256, 128, 0), (256, 256, 272, 1)])
+def test_gemm_nt_against_numpy(M, N, K, lower):
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K)
+    B = rng.randn(N, K) + np.arange(N)[:, None] * 0.01      # asymmetric on purpose
+    C0 = rng.randn(M, N)
+    a, b, c = _dev(A), _dev(B), _dev(C0)
+    st = _gpx.lib.gpx_dev_gemm_nt(_p(a), K, _p(b), K, _p(c), N, M, N, K, -0.75, 1.25, lower, None)
+    _gpx.check(st, "gemm")
+    torch.cuda.synchronize()
+    got = c.cpu().numpy()
+    want = -0.75 * A.dot(B.T) + 1.25 * C0
+    if lower:   # tiles above the diagonal are untouched
+        for bi in range(M // 128):
+            for bj in range(N // 128):
+                blk = (slice(128 * bi, 128 * bi + 128), slice(128 * bj, 128 * bj + 128))
+                np.testing.assert_allclose(got[blk], want[blk] if bj <= bi else C0[blk], rtol=1e-13, atol=1e-12)
+    else:
+        np.testing.assert_allclose(got, want, rtol=1e-13, atol=1e-12)
+    # beta = 0 must ignore (possibly NaN) C
+    c2 = torch.full((M, N), float("nan"), dtype=torch.float64, device="cuda")
+    _gpx.check(_gpx.lib.gpx_dev_gemm_nt(_p(a), K, _p(b), K, _p(c2), N, M, N, K, 1.0, 0.0, 0, None), "gemm")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(c2.cpu().numpy(), A.dot(B.T), rtol=1e-13, atol=1e-12)
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(128, 16, dtype=torch.float64, device="cuda")
+    assert _gpx.lib.gpx_dev_gemm_nt(_p(a), 16, _p(a), 16, _p(a), 128, 100, 128, 16, 1.0, 0.0, 0, None) == _gpx.GPX_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e8])
+def test_potrf_leaf_and_inverse(cond):
+    rng = np.random.RandomState(3)
+    Q, _ = np.linalg.qr(rng.randn(128, 128))
+    ev = np.logspace(0, np.log10(cond), 128)
+    A = (Q * ev).dot(Q.T)
+    A = 0.5 * (A + A.T)
+    ld = 256
+    buf = np.full((128, ld), np.nan)
+    buf[:, :128] = A
+    a = _dev(buf)
+    dinv = torch.empty(128 * 128, dtype=torch.float64, device="cuda")
+    diag = torch.empty(128, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _gpx.check(_gpx.lib.gpx_dev_potrf_leaf(_p(a), ld, _p(dinv), _p(diag), _p(info), 0, None), "potrf leaf")
+    torch.cuda.synchronize()
+    assert int(info.item()) == 0
+    L = a.cpu().numpy()[:, :128]
+    Lref = np.linalg.cholesky(A)
+    assert np.all(np.triu(L, 1) == 0)
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-13 * cond ** 0.5 * np.abs(Lref).max())
+    np.testing.assert_allclose(diag.cpu().numpy(), np.diag(Lref), rtol=1e-12 * cond ** 0.5)
+    X = dinv.cpu().numpy().reshape(128, 128)
+    assert np.all(np.triu(X, 1) == 0)
+    np.testing.assert_allclose(X.dot(L), np.eye(128), rtol=0, atol=1e-12 * cond ** 0.5)
+
+
+def test_potrf_leaf_reports_non_pd():
+    A = np.eye(128)
+    A[40, 40] = -1.0
+    a = _dev(A)
+    dinv = torch.empty(128 * 128, dtype=torch.float64, device="cuda")
+    diag = torch.empty(128, dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _gpx.check(_gpx.lib.gpx_dev_potrf_leaf(_p(a), 128, _p(dinv), _p(diag), _p(info), 1000, None), "potrf leaf")
+    torch.cuda.synchronize()
+    assert int(info.item()) == 1041
+
+
+# ------------------------------------------------------------------------------------------------
+# Gram (a1/a2)
+# ------------------------------------------------------------------------------------------------
+GRAM_CASES = ["grid_int", "n257_d5", "n64_d16", "rect_33x257_d5", "n257_d5_vt0", "n130_d1"]
+
+
+@pytest.mark.parametrize("name", GRAM_CASES)
+def test_gram_golden(name):
+    g = load_golden("gram")
+    xi, xj, th = g[name + "__xi"], g[name + "__xj"], g[name + "__theta"]
+    cov = sk.GaussianCovariance()
+    K = cov.cov_matrix_ij(xi, xj, th)
+    np.testing.assert_allclose(K, g[name + "__K_ij"], rtol=1e-13, atol=1e-300)
+    if name + "__K" in g:
+        Kf = cov.cov_matrix(xi, th)
+        np.testing.assert_allclose(Kf, g[name + "__K"], rtol=1e-13, atol=1e-300)
+        # the reference's own identity test (skgpuppy/tests/tests.py:598-600): cov_matrix == cov_matrix_ij + vt I
+        with np.errstate(divide="ignore"):
+            vt = np.exp(th[1])
+        assert np.abs(Kf - (K + vt * np.eye(len(xi)))).sum() <= 1e-10
+
+
+def test_gram_empty_and_single():
+    cov = sk.GaussianCovariance()
+    th = np.zeros(5)
+    assert cov.cov_matrix_ij(np.zeros((0, 3)), np.zeros((4, 3)), th).shape == (0, 4)
+    K = cov.cov_matrix(np.ones((1, 3)), th)
+    assert K.shape == (1, 1) and K[0, 0] == pytest.approx(2.0)
+
+
+# ------------------------------------------------------------------------------------------------
+# GP cases against golden vectors of the reference
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=GP_CASES)
+def case(request):
+    g = load_golden(request.param)
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    return request.param, g, gp
+
+
+def _loose(name):
+    return 10.0 if name == "metis" else 1.0
+
+
+def test_fit_golden(case):
+    name, g, gp = case
+    assert gp.meant == pytest.approx(float(g["meant"]), abs=1e-15)
+    np.testing.assert_allclose(gp.t, g["t_centered"], rtol=0, atol=1e-15)
+    beta = gp._get_beta()
+    np.testing.assert_allclose(beta, g["beta"], rtol=0, atol=1e-6 * _loose(name) * np.abs(g["beta"]).max())
+    assert gp._dev().logdet() == pytest.approx(float(g["logdet"]), rel=1e-9, abs=1e-7)
+    assert gp._dev().jitter() == 0.0
+    if "Kinv" in g:
+        Kinv = gp.Kinv
+        assert Kinv.shape == (gp.n, gp.n)
+        np.testing.assert_allclose(Kinv, g["Kinv"], rtol=0, atol=1e-7 * np.abs(g["Kinv"]).max())
+        np.testing.assert_allclose(Kinv, Kinv.T, rtol=0, atol=0)
+
+
+def test_cholesky_reconstructs_K(case):
+    name, g, gp = case
+    L = gp._dev().chol()
+    with np.errstate(divide="ignore"):
+        K = orc.gram(g["x"], g["theta"])
+    np.testing.assert_allclose(L.dot(L.T), K, rtol=0, atol=1e-12 * np.abs(K).max())
+
+
+def test_estimate_many_golden(case):
+    name, g, gp = case
+    v = np.exp(g["theta"][0])
+    mean, var = gp.estimate_many(g["xs"])
+    k = _loose(name)
+    np.testing.assert_allclose(mean, g["pred_mean"], rtol=1e-6 * k, atol=1e-9 * k)
+    np.testing.assert_allclose(var, g["pred_var"], rtol=1e-6 * k, atol=1e-9 * v * k)
+    m0, v0 = gp.estimate(g["xs"][0])
+    assert m0 == pytest.approx(g["est0"][0], rel=1e-6 * k, abs=1e-9 * k)
+    assert v0 == pytest.approx(g["est0"][1], rel=1e-6 * k, abs=1e-9 * v * k)
+    m1, v1 = gp(g["xs"][0])
+    assert (m1, v1) == (m0, v0)
+    # list input, as the README passes it
+    ml, vl = gp.estimate_many([list(r) for r in g["xs"][:3]])
+    np.testing.assert_array_equal(ml, mean[:3])
+    np.testing.assert_array_equal(vl, var[:3])
+
+
+def test_propagation_golden(case):
+    name, g, gp = case
+    v = np.exp(g["theta"][0])
+    k = _loose(name)
+    for iu in range(int(g["nu"])):
+        u = g["u%d" % iu]
+        for iS in range(int(g["nS"])):
+            S = g["Sigma%d" % iS]
+            upa = sk.UncertaintyPropagationApprox(gp)
+            ma, va = upa.propagate_GA(u, S)
+            ref = g["approx_u%d_S%d" % (iu, iS)]
+            assert ma == pytest.approx(ref[0], abs=1e-9 * k)
+            assert va == pytest.approx(ref[1], abs=1e-8 * v * k)
+            assert upa.propagate_mean(u, S) == pytest.approx(float(g["approx_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
+            f = upa._getFactor(u, S, float(g["v_out"]))
+            assert f == pytest.approx(float(g["factor_u%d_S%d" % (iu, iS)]), rel=1e-5 * k)
+            if iS == 0:
+                np.testing.assert_allclose(upa.C_ux, g["C_ux_u%d" % iu], rtol=1e-13, atol=1e-300)
+                np.testing.assert_allclose(upa.J_ux, g["J_ux_u%d" % iu], rtol=1e-12, atol=1e-300)
+                np.testing.assert_allclose(upa.H_ux, g["H_ux_u%d" % iu], rtol=1e-12, atol=1e-300)
+                dv = np.array([upa._get_variance_dv_h(u, h) for h in range(gp.d)])
+                np.testing.assert_allclose(dv, g["dvh_u%d" % iu], rtol=1e-6 * k, atol=1e-8 * v * k)
+            key = "exact_u%d_S%d" % (iu, iS)
+            if key in g:
+                upe = sk.UncertaintyPropagationExact(gp)
+                me, ve = upe.propagate_GA(u, S)
+                assert me == pytest.approx(g[key][0], abs=1e-9 * k)
+                assert ve == pytest.approx(g[key][1], abs=1e-8 * v * k)
+                assert upe.propagate_mean(u, S) == pytest.approx(float(g["exact_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
+
+
+def test_kat1_quirk_active():
+    """u equal to a training row: the +vt-on-equality quirk of the scalar kernel must be reproduced."""
+    g = load_golden("kat1_grid")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    S = np.diag([0.01, 0.01])
+    u = np.array([5.0, 5.0])
+    assert sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S) == pytest.approx(
+        (0.18983893618073702, 0.0018348329974112298), abs=1e-9)
+    assert sk.UncertaintyPropagationExact(gp).propagate_GA(u, S) == pytest.approx(
+        (0.18981740098493302, 0.0018392233503982257), abs=1e-9)
+
+
+def test_metis_reference_assertions():
+    """The reference's own METIS test (skgpuppy/tests/tests.py:1381-1409) at the fixed theta of KAT2."""
+    g = load_golden("metis")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    u = np.array([15.05, 5.0, 0.025])
+    S = np.diag([4.0, 1.0, 2.5e-5])
+    meanG, varG = gp(u)
+    code_u = varG - gp._get_vt()
+    assert np.sqrt(code_u) < 0.0006
+    for cls in (sk.UncertaintyPropagationExact, sk.UncertaintyPropagationApprox):
+        m, var = cls(gp).propagate_GA(u, S)
+        assert 0.0410788036621 < np.sqrt(var - code_u) < 0.0422334526251
+
+
+# ------------------------------------------------------------------------------------------------
+# oracle parity on fresh seeded inputs, ragged sizes and edge cases
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,d,M", [(1, 2, 3), (2, 1, 1), (127, 3, 5), (128, 3, 129), (129, 5, 1), (640, 6, 300), (1500, 8, 257)])
+def test_against_oracle_ragged(N, d, M):
+    rng = np.random.RandomState(100 + N + d)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    og = orc.OracleGP(x, t, theta)
+    mean, var = gp.estimate_many(xs)
+    om, ov = og.estimate_many(xs)
+    np.testing.assert_allclose(mean, om, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(var, ov, rtol=1e-6, atol=2e-9)
+    np.testing.assert_allclose(gp._get_beta(), og.beta(), rtol=0, atol=1e-6 * np.abs(og.beta()).max())
+    assert gp._dev().logdet() == pytest.approx(og.logdet(), rel=1e-9, abs=1e-7)
+    if N >= 2:
+        u = xs[0]
+        S = np.diag(rng.uniform(0.005, 0.05, d))
+        ma, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+        oma, ova = orc.approx_propagate(og, u, S)
+        assert ma == pytest.approx(oma, abs=1e-9) and va == pytest.approx(ova, abs=2e-8)
+        me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
+        ome, ove = orc.exact_propagate(og, u, S)
+        assert me == pytest.approx(ome, abs=1e-9) and ve == pytest.approx(ove, abs=2e-8)
+
+
+def test_zero_queries():
+    g = load_golden("kat1_grid")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    mean, var = gp.estimate_many(np.zeros((0, 2)))
+    assert mean.shape == (0,) and var.shape == (0,)
+
+
+def test_pickle_roundtrip_bit_identical():
+    """skgpuppy/tests/tests.py:626-659: protocol 0, estimate_many identical after reload."""
+    g = load_golden("n203_d3")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    m0, v0 = gp.estimate_many(g["xs"])
+    gp2 = pickle.loads(pickle.dumps(gp, protocol=0))
+    m1, v1 = gp2.estimate_many(g["xs"])
+    np.testing.assert_array_equal(m0, m1)
+    np.testing.assert_array_equal(v0, v1)
+    for attr in ("n", "d", "meant"):
+        assert getattr(gp2, attr) == getattr(gp, attr)
+    np.testing.assert_array_equal(gp2.theta_min, gp.theta_min)
+
+
+def test_jitter_fallback_on_singular_K():
+    """Duplicate rows with vt = 0 make K exactly singular: the reference falls back to chol(K + 1e-5 I)
+    (skgpuppy/Covariance.py:180-185)."""
+    rng = np.random.RandomState(5)
+    x = rng.uniform(0, 3, (40, 2))
+    x[7] = x[3]
+    t = rng.randn(40)
+    theta = np.array([0.0, -np.inf, 0.0, 0.0])
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta)
+    assert gp._dev().jitter() == 1e-5
+    with np.errstate(divide="ignore"):
+        K = orc.gram(x, theta) + 1e-5 * np.eye(40)
+    np.testing.assert_allclose(gp.Kinv.dot(K), np.eye(40), atol=1e-6)
+
+
+def test_bad_arguments_raise():
+    cov = sk.GaussianCovariance()
+    with pytest.raises(ValueError):
+        cov.cov_matrix_ij(np.zeros((3, 2)), np.zeros((3, 3)), np.zeros(4))
+    with pytest.raises(ValueError):
+        cov.cov_matrix_ij(np.zeros((3, 2)), np.zeros((3, 2)), np.zeros(5))
+    x = np.random.RandomState(0).rand(10, 2)
+    gp = sk.GaussianProcess(x, np.zeros(10), cov, np.zeros(4))
+    with pytest.raises(ValueError):
+        gp.estimate_many(np.zeros((3, 5)))
+    with pytest.raises(ValueError):
+        sk.UncertaintyPropagationApprox(gp).propagate_GA(np.zeros(3), np.eye(2))
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE sizes: size-independent properties (the oracle cannot run these in seconds)
+# ------------------------------------------------------------------------------------------------
+def _recipe(N, d, M):
+    rng = np.random.RandomState(20240 + N + d)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    return x, t, xs, theta
+
+
+@pytest.mark.parametrize("N,d", [(4096, 4), (16384, 8)])
+def test_full_size_properties(N, d):
+    x, t, xs, theta = _recipe(N, d, 2048)
+    cov = sk.GaussianCovariance()
+    gp = sk.GaussianProcess(x, t, cov, theta.copy())
+    v, vt = 2.0, 0.01
+    # (1) K alpha = t : residual through an independent path (Gram rows from the Gram kernel, host GEMV)
+    beta = gp._get_beta()
+    rows = np.random.RandomState(1).choice(N, 512, replace=False)
+    Krows = cov.cov_matrix_ij(x[rows], x, theta)
+    Krows[np.arange(512), rows] += vt
+    resid = Krows.dot(beta) - gp.t[rows]
+    assert np.abs(resid).max() < 1e-8 * max(1.0, np.abs(beta).max())
+    # (2) interpolation identity at training inputs: mean_i = t_i - vt alpha_i ; var_i = 2 vt - vt^2 Kinv_ii in [vt, 2 vt)
+    mean, var = gp.estimate_many(x[rows])
+    np.testing.assert_allclose(mean - gp.meant, gp.t[rows] - vt * beta[rows], rtol=0, atol=1e-8)
+    assert np.all(var >= vt - 1e-9) and np.all(var < 2 * vt)
+    # (3) far-away query: prior
+    far = np.full((1, d), 1e3)
+    mf, vf = gp.estimate_many(far)
+    assert mf[0] == pytest.approx(gp.meant, abs=1e-12) and vf[0] == pytest.approx(v + vt, abs=1e-12)
+    # (4) permutation equivariance + chunk independence of estimate_many
+    m2, v2 = gp.estimate_many(xs[::-1])
+    m1, v1 = gp.estimate_many(xs)
+    np.testing.assert_array_equal(m1, m2[::-1])
+    np.testing.assert_array_equal(v1, v2[::-1])
+    # (5) propagation with vanishing input uncertainty reduces to the plain prediction
+    u = xs[0]
+    S0 = 1e-14 * np.eye(d)
+    mu, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S0)
+    me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S0)
+    assert mu == pytest.approx(m1[0], abs=1e-8) and me == pytest.approx(m1[0], abs=1e-8)
+    assert va == pytest.approx(v1[0], abs=1e-7) and ve == pytest.approx(v1[0], abs=1e-7)
+    # (6) Exact vs Approx agree to second order for small Sigma (reference tests.py:1200-1242 uses 1e-2)
+    S = 0.01 * np.eye(d)
+    mu, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(np.full(d, 5.0), S)
+    me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(np.full(d, 5.0), S)
+    assert mu == pytest.approx(me, abs=1e-2) and va == pytest.approx(ve, abs=1e-2)
