@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: GP fit + estimate_many points/second on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+
+One "step" = one pass of the hot path over one batch of synthetic input:
+fit (Gram + vt I -> blocked fp64 Cholesky -> alpha) followed by estimate_many on M = N queries.
+Inputs (x, t, xs) are resident in HBM before the timed region; outputs stay on the device.
+value = (N + M) * steps / time   [pts/s], fp64 throughout.
+
+N=1 : BASELINE.json config C3 (N=16384, d=8, M=16384), the configuration the metric is quoted on.
+N>1 : one rank per GPU (torch.distributed over RCCL), config C4 (N=65536, d=16) with the K panels
+      sharded block-cyclically across ranks (strong scaling) -- see DESIGN.md "multi-GPU".
+
+The JSON line also carries
+  roofline     : the dominant kernel (fp64 MFMA GEMM) timed live with HIP events on the handle's stream
+  cpu_baseline : the oracle (CPU restatement of the reference algorithm, "port") timed on the host
+                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "scikit-gpuppy_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (before libgpx: one shared HIP runtime)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix peak; re-measured below
+HBM_PEAK_GBS = 8000.0
+
+WORKLOADS = {
+    "c2": dict(N=4096, d=4, M=4096),
+    "c3": dict(N=16384, d=8, M=16384),
+    "c4": dict(N=65536, d=16, M=65536),
+}
+
+
+def recipe(N, d, M):
+    """BASELINE.md section 3 synthetic inputs."""
+    rng = np.random.RandomState(20240 + N + d)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    return x, t, xs, theta
+
+
+def cpu_baseline(d, budget_n=5120):
+    """Time the oracle (same algorithm class as the reference: tile/GEMM Gram, LU inverse, GEMM-based
+    estimate_many with the M x M products) on a bounded sample of the workload."""
+    from oracle import oracle as orc
+    N = M = budget_n
+    x, t, xs, theta = recipe(N, d, M)
+    t0 = time.perf_counter()
+    gp = orc.OracleGP(x, t, theta)
+    t1 = time.perf_counter()
+    gp.estimate_many(xs)
+    t2 = time.perf_counter()
+    return N, M, t1 - t0, t2 - t1
+
+
+def run_single(args):
+    import skgpuppy_amd  # noqa: F401
+    from skgpuppy_amd import _gpx
+
+    wl = WORKLOADS[args.workload or "c3"]
+    N, d, M = wl["N"], wl["d"], wl["M"]
+    x, t, xs, theta = recipe(N, d, M)
+    tc = t - t.mean()
+    dev = torch.device("cuda:0")
+    xd = torch.as_tensor(x).to(dev)
+    td = torch.as_tensor(tc).to(dev)
+    xsd = torch.as_tensor(xs).to(dev)
+    mean_d = torch.empty(M, dtype=torch.float64, device=dev)
+    var_d = torch.empty(M, dtype=torch.float64, device=dev)
+    th = np.ascontiguousarray(theta)
+    torch.cuda.synchronize()
+    lib = _gpx.lib
+    vp = lambda tt: ctypes.c_void_p(tt.data_ptr())  # noqa: E731
+
+    prof = {k: [0, 0.0, 0.0] for k in range(7)}
+    t_fit = [0.0]
+    t_pred = [0.0]
+
+    def step(timed):
+        h = ctypes.c_void_p()
+        a = time.perf_counter()
+        _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "gpx_fit")
+        b = time.perf_counter()
+        if timed:
+            lib.gpx_profile_enable(h, 1)
+        _gpx.check(lib.gpx_predict(h, vp(xsd), M, vp(mean_d), vp(var_d)), "gpx_predict")
+        c = time.perf_counter()
+        if timed:
+            t_fit[0] += b - a
+            t_pred[0] += c - b
+            for k in range(7):
+                n_, ms_, w_ = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+                lib.gpx_profile_read(h, k, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(w_))
+                prof[k][0] += n_.value
+                prof[k][1] += ms_.value
+                prof[k][2] += w_.value
+        lib.gpx_free(h)
+
+    # fit-side kernels are profiled through a process-wide switch so that gpx_fit itself is covered
+    os.environ["GPX_PROFILE"] = "1"
+    for _ in range(args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    value = (N + M) * args.steps / elapsed
+    g_n, g_ms, g_flops = prof[_gpx.K_GEMM]
+    achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+    mf = ctypes.c_double()
+    lib.gpx_bench_mfma_f64(4000, ctypes.byref(mf))
+
+    out = {
+        "metric": "GP fit+predict pts/sec (K+Cholesky, N=%d d=%d)" % (N, d),
+        "value": value,
+        "unit": "pts/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "%s: N=%d d=%d M=%d fit(Gram+Cholesky+alpha)+estimate_many, theta fixed" % (
+            (args.workload or "c3").upper(), N, d, M), "global_batch": N + M, "parallelism": "1 GPU"},
+        "fit_ms": t_fit[0] / args.steps * 1e3,
+        "predict_ms": t_pred[0] / args.steps * 1e3,
+        "roofline": {
+            "kernel": "gemm_nt_f64_kernel (v_mfma_f64_16x16x4_f64)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_per_step": g_n / max(1, args.steps),
+            "avg_launch_ms": g_ms / max(1, g_n),
+            "flops_per_step": g_flops / max(1, args.steps),
+            "measured_mfma_f64_issue_peak": mf.value,
+        },
+        "kernel_classes": {
+            _gpx.KERNEL_CLASS_NAMES[k]: {"launches": prof[k][0] / args.steps, "ms": prof[k][1] / args.steps,
+                                         "work": prof[k][2] / args.steps} for k in range(7) if prof[k][0]},
+    }
+    if not args.no_cpu:
+        Ns, Ms, tf, tp = cpu_baseline(d)
+        v_s = (Ns + Ms) / (tf + tp)
+        scale = (N / Ns) ** 3
+        out["cpu_baseline"] = {
+            "value": v_s,
+            "unit": "pts/s",
+            "cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "oracle (numpy/scipy restatement of the reference algorithm) on N=M=%d d=%d of the same recipe: "
+                      "fit %.2f s + estimate_many %.2f s; cubic extrapolation to N=M=%d: %.1f pts/s" % (
+                          Ns, d, tf, tp, N, (N + M) / ((tf + tp) * scale)),
+            "extrapolated_full_workload_value": (N + M) / ((tf + tp) * scale),
+        }
+    print(json.dumps(out))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from skgpuppy_amd import distributed as dist_mod
+        dist_mod.bench_main(args)
+        return
+    run_single(args)
+
+
+if __name__ == "__main__":
+    main()

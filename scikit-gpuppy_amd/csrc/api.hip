@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -278,6 +279,7 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
     }
     hipStream_t s = h->stream;
     auto fail = [&](int code) { gpx_free(h); return code; };
+    if (const char *pe = getenv("GPX_PROFILE")) h->prof.on = (pe[0] == '1');   // covers the kernels of gpx_fit itself
 
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
