@@ -123,6 +123,9 @@ int gpx_profile_read(gpx_handle *h, int kernel_class, int64_t *launches, double 
 /* ---- device micro-benchmarks used to re-verify the roofline denominators on the box ---- */
 int gpx_bench_mfma_f64(int iters, double *tflops);          /* back-to-back v_mfma_f64_16x16x4_f64 */
 int gpx_bench_hbm(int64_t bytes, int iters, double *write_gbs, double *copy_gbs);
+/* mode 0: MFMA f64 only, 1: VALU v_fma_f64 only, 2: half the waves each; `blocks` workgroups of 4 waves.
+ * cycles_per_inst from s_memtime, clock_ghz from s_memtime / s_memrealtime (the clock held under load). */
+int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tflops, double *cycles_per_inst, double *clock_ghz);
 
 /* ---- building blocks on device pointers (used by the multi-GPU host and by tests) ----
  * All pointers are DEVICE pointers; leading dimensions in elements; sizes multiples of GPX_TILE. */

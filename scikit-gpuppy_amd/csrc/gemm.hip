@@ -192,6 +192,90 @@ extern "C" int gpx_bench_mfma_f64(int iters, double *tflops)
     return 0;
 }
 
+// ---- diagnostic: cycles per instruction and the clock the chip holds under an fp64 MFMA / VALU load ----
+// mode 0: every wave issues MFMA f64; mode 1: every wave issues packed-free VALU v_fma_f64;
+// mode 2: even waves MFMA, odd waves VALU (do the two pipes add up, or is the chip power-bound?)
+__global__ __launch_bounds__(256) void fp64_pipe_kernel(double *out, unsigned long long *stamps, int iters, int mode)
+{
+    const int wave = threadIdx.x >> 6;
+    const bool use_mfma = (mode == 0) || (mode == 2 && (wave & 1) == 0);
+    v4d acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 0.999 - threadIdx.x * 1e-3;
+    double f[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) f[i] = a * (i + 1);
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    if (use_mfma) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = fma(f[i], b, a);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += f[i];
+    out[(long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) {
+        const long w = (long)blockIdx.x * 4 + wave;
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
+extern "C" int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tflops, double *cycles_per_inst,
+                                    double *clock_ghz)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        gpx_set_error("no HIP device");
+        return GPX_ERR_NO_DEVICE;
+    }
+    if (blocks < 1 || iters < 1 || mode < 0 || mode > 2) return GPX_ERR_BAD_ARG;
+    double *out = nullptr;
+    unsigned long long *st = nullptr;
+    GPX_HIP(hipMalloc(&out, sizeof(double) * blocks * 256));
+    GPX_HIP(hipMalloc(&st, sizeof(unsigned long long) * blocks * 8));
+    hipEvent_t e0, e1;
+    GPX_HIP(hipEventCreate(&e0));
+    GPX_HIP(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; ++rep)   // warm the clock governor
+        hipLaunchKernelGGL(fp64_pipe_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, mode);
+    GPX_HIP(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL(fp64_pipe_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, mode);
+    GPX_HIP(hipEventRecord(e1, 0));
+    GPX_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    GPX_HIP(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h((size_t)blocks * 8);
+    GPX_HIP(hipMemcpy(h.data(), st, sizeof(unsigned long long) * blocks * 8, hipMemcpyDeviceToHost));
+    double cyc = 0, rt = 0;
+    for (int w = 0; w < blocks * 4; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
+    const double waves = blocks * 4.0;
+    double n_mfma_waves = (mode == 0) ? waves : (mode == 2 ? waves / 2 : 0);
+    double n_valu_waves = waves - n_mfma_waves;
+    double flops = n_mfma_waves * (double)iters * 8.0 * 2048.0 + n_valu_waves * (double)iters * 32.0 * 128.0;
+    if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
+    if (cycles_per_inst) *cycles_per_inst = (cyc / waves) / ((double)iters * (mode == 1 ? 32.0 : 8.0));
+    if (clock_ghz) *clock_ghz = (cyc / rt) * 0.1;   // s_memrealtime ticks at 100 MHz
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(out);
+    (void)hipFree(st);
+    return 0;
+}
+
 extern "C" int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                                int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream)
 {

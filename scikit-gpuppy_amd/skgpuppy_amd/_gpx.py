@@ -56,6 +56,7 @@ SIGNATURES = {
     "gpx_profile_read": (_int, [_hp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_bench_mfma_f64": (_int, [_int, ctypes.POINTER(_dbl)]),
     "gpx_bench_hbm": (_int, [_i64, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "gpx_bench_fp64_pipes": (_int, [_int, _int, _int] + [ctypes.POINTER(_dbl)] * 3),
     "gpx_dev_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
     "gpx_dev_gemm_nt": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, _int, ctypes.c_void_p]),
     "gpx_dev_potrf_leaf": (_int, [_dp, _i64, _dp, _dp, ctypes.c_void_p, _int, ctypes.c_void_p]),
