@@ -12,7 +12,8 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int TILE = GPX_TILE;       // 128: diagonal-block size, GEMM block tile
 constexpr int GEMM_BK = 16;          // k-depth of one LDS stage
-constexpr int GEMM_LDS_S = 18;       // padded LDS row stride in doubles (S/2 odd -> conflict-free ds_read_b64 fragments)
+constexpr int GEMM_LDS_S = 17;       // padded LDS row stride in doubles: ODD, so the ds_read2_b64 fragment reads the compiler
+                                     // emits (16-lane groups, 32 banks) are conflict free; staged with 8-byte LDS writes
 
 // ---- error plumbing ---------------------------------------------------------------------
 void gpx_set_error(const char *fmt, ...);

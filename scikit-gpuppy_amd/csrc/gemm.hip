@@ -10,8 +10,8 @@
 // Tiling: 128x128 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles of 16x16 (16
 // independent accumulators, 128 VGPRs).  k is staged 16 deep through double-buffered LDS with one
 // barrier per stage; global loads are 16 B/lane with 8 lanes covering one 128-B row segment; LDS
-// rows are padded to 18 doubles so the per-lane ds_read_b64 fragment reads (lane l -> row l&15,
-// k l>>4) are bank-conflict free.  LDS 72 KiB/block -> 2 blocks per CU.
+// rows are padded to an odd stride (17 doubles) so the ds_read2_b64 fragment reads (lane l -> row l&15,
+// k l>>4) are bank-conflict free.  LDS 68 KiB/block -> 2 blocks per CU.
 #include "common.h"
 
 constexpr int BM = 128, BN = 128;
@@ -24,7 +24,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     __shared__ __attribute__((aligned(16))) double As[2][BM * GEMM_LDS_S];
     __shared__ __attribute__((aligned(16))) double Bs[2][BN * GEMM_LDS_S];
 
-    const int bx = blockIdx.x, by = blockIdx.y;   // bx: column tile, by: row tile
+    // Block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD a
+    // contiguous chunk of the logical tile order, and walk that order in groups of GM row tiles so that the
+    // tiles resident on one XCD share A row panels and B column panels in its L2 (speed only, never correctness).
+    int bx, by;   // bx: column tile, by: row tile
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy;
+        const int orig = blockIdx.y * gx + blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
+        constexpr int GM = 8;
+        const int per_group = GM * gx;
+        const int g = lid / per_group, rem = lid - g * per_group;
+        const int first = g * GM;
+        const int rows = (gy - first) < GM ? (gy - first) : GM;
+        by = first + rem % rows;
+        bx = rem / rows;
+    }
     if (LOWER && bx > by) return;
 
     const int t = threadIdx.x;
@@ -50,8 +67,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<v2d *>(&As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = ga[i];
-        *reinterpret_cast<v2d *>(&Bs[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = gb[i];
+        double *pa = &As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+        double *pb = &Bs[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+        pa[0] = ga[i].x; pa[1] = ga[i].y;
+        pb[0] = gb[i].x; pb[1] = gb[i].y;
     }
     __syncthreads();
 
@@ -59,9 +78,27 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     const int a_off = (wr * 64 + fr) * GEMM_LDS_S + fq;
     const int b_off = (wc * 64 + fr) * GEMM_LDS_S + fq;
 
+    // Software pipeline.  Fragments are double buffered in registers (set 0/1) one 4-deep k-slice ahead,
+    // the next stage's global tile is fetched at the top of the stage, written to the other LDS buffer
+    // after the second slice, and the stage barrier sits BEFORE the last slice's MFMAs so that the first
+    // fragments of the next stage are read while those MFMAs run: no LDS or HBM latency is exposed between
+    // two MFMA groups, only wave skew at the barrier.
+    double fa[2][4], fb[2][4];
+#define GPX_LOAD_FRAGS(SET, BUF, KK)                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+        fa[SET][i_] = As[BUF][a_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];                \
+        fb[SET][i_] = Bs[BUF][b_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];                \
+    }
+#define GPX_MMA(SET)                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                               \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i_], fb[SET][j_], acc[i_][j_], 0, 0, 0);
+
+    GPX_LOAD_FRAGS(0, 0, 0)
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
+        const int cur = kt & 1, nxt = cur ^ 1;
+        const bool has_next = kt + 1 < nk;
+        if (has_next) {
             const double *Ak = Ag + (long)(kt + 1) * GEMM_BK;
             const double *Bk = Bg + (long)(kt + 1) * GEMM_BK;
 #pragma unroll
@@ -70,32 +107,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
                 gb[i] = *reinterpret_cast<const v2d *>(Bk + (long)(32 * i) * ldb);
             }
         }
-        const double *as = &As[cur][a_off];
-        const double *bs = &Bs[cur][b_off];
-#pragma unroll
-        for (int kk = 0; kk < GEMM_BK / 4; ++kk) {
-            double af[4], bf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = as[i * 16 * GEMM_LDS_S + kk * 4];
-                bf[i] = bs[i * 16 * GEMM_LDS_S + kk * 4];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            const int nxt = cur ^ 1;
+        GPX_LOAD_FRAGS(1, cur, 1)
+        GPX_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        GPX_LOAD_FRAGS(0, cur, 2)
+        GPX_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<v2d *>(&As[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = ga[i];
-                *reinterpret_cast<v2d *>(&Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc]) = gb[i];
+                double *pa = &As[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+                double *pb = &Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+                pa[0] = ga[i].x; pa[1] = ga[i].y;
+                pb[0] = gb[i].x; pb[1] = gb[i].y;
             }
         }
+        GPX_LOAD_FRAGS(1, cur, 3)
+        GPX_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
+        if (has_next) { GPX_LOAD_FRAGS(0, nxt, 0) }
+        GPX_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
     }
+#undef GPX_LOAD_FRAGS
+#undef GPX_MMA
 
     // epilogue: accumulator register r of tile (i,j) is C[row = fq + 4r][col = fr] of that 16x16 tile
     double *Cw = C + ((long)by * BM + wr * 64 + fq) * ldc + (long)bx * BN + wc * 64 + fr;
@@ -234,6 +270,33 @@ __global__ __launch_bounds__(256) void fp64_pipe_kernel(double *out, unsigned lo
     }
 }
 
+// mode 10+k: MFMA f64 with 2^k independent accumulators per wave (k = 0..5): issue interval vs dependent latency
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_chain_kernel(double *out, unsigned long long *stamps, int iters)
+{
+    v4d acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 0.999 - threadIdx.x * 1e-3;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    out[(long)blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) {
+        const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
 extern "C" int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tflops, double *cycles_per_inst,
                                     double *clock_ghz)
 {
@@ -242,7 +305,7 @@ extern "C" int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tfl
         gpx_set_error("no HIP device");
         return GPX_ERR_NO_DEVICE;
     }
-    if (blocks < 1 || iters < 1 || mode < 0 || mode > 2) return GPX_ERR_BAD_ARG;
+    if (blocks < 1 || iters < 1 || mode < 0 || (mode > 2 && (mode < 10 || mode > 15))) return GPX_ERR_BAD_ARG;
     double *out = nullptr;
     unsigned long long *st = nullptr;
     GPX_HIP(hipMalloc(&out, sizeof(double) * blocks * 256));
@@ -250,10 +313,21 @@ extern "C" int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tfl
     hipEvent_t e0, e1;
     GPX_HIP(hipEventCreate(&e0));
     GPX_HIP(hipEventCreate(&e1));
-    for (int rep = 0; rep < 3; ++rep)   // warm the clock governor
-        hipLaunchKernelGGL(fp64_pipe_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, mode);
+    int nacc = 8;
+    auto launch = [&]() {
+        switch (mode) {
+        case 10: nacc = 1; hipLaunchKernelGGL(mfma_chain_kernel<1>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        case 11: nacc = 2; hipLaunchKernelGGL(mfma_chain_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        case 12: nacc = 4; hipLaunchKernelGGL(mfma_chain_kernel<4>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        case 13: nacc = 8; hipLaunchKernelGGL(mfma_chain_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        case 14: nacc = 16; hipLaunchKernelGGL(mfma_chain_kernel<16>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        case 15: nacc = 32; hipLaunchKernelGGL(mfma_chain_kernel<32>, dim3(blocks), dim3(256), 0, 0, out, st, iters); break;
+        default: hipLaunchKernelGGL(fp64_pipe_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, mode);
+        }
+    };
+    for (int rep = 0; rep < 3; ++rep) launch();   // warm the clock governor
     GPX_HIP(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(fp64_pipe_kernel, dim3(blocks), dim3(256), 0, 0, out, st, iters, mode);
+    launch();
     GPX_HIP(hipEventRecord(e1, 0));
     GPX_HIP(hipEventSynchronize(e1));
     float ms = 0;
@@ -263,11 +337,11 @@ extern "C" int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tfl
     double cyc = 0, rt = 0;
     for (int w = 0; w < blocks * 4; ++w) { cyc += (double)h[2 * w]; rt += (double)h[2 * w + 1]; }
     const double waves = blocks * 4.0;
-    double n_mfma_waves = (mode == 0) ? waves : (mode == 2 ? waves / 2 : 0);
+    double n_mfma_waves = (mode == 0 || mode >= 10) ? waves : (mode == 2 ? waves / 2 : 0);
     double n_valu_waves = waves - n_mfma_waves;
-    double flops = n_mfma_waves * (double)iters * 8.0 * 2048.0 + n_valu_waves * (double)iters * 32.0 * 128.0;
+    double flops = n_mfma_waves * (double)iters * (double)nacc * 2048.0 + n_valu_waves * (double)iters * 32.0 * 128.0;
     if (tflops) *tflops = flops / (ms * 1e-3) / 1e12;
-    if (cycles_per_inst) *cycles_per_inst = (cyc / waves) / ((double)iters * (mode == 1 ? 32.0 : 8.0));
+    if (cycles_per_inst) *cycles_per_inst = (cyc / waves) / ((double)iters * (mode == 1 ? 32.0 : (double)nacc));
     if (clock_ghz) *clock_ghz = (cyc / rt) * 0.1;   // s_memrealtime ticks at 100 MHz
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
