@@ -241,6 +241,7 @@ extern "C" void gpx_free(gpx_handle *h)
     for (double *p : bufs)
         if (p) (void)hipFree(p);
     if (h->info_dev) (void)hipFree(h->info_dev);
+    if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); (void)hipStreamDestroy(h->s_pan); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -250,7 +251,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, &h->prof));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -278,6 +279,11 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
         h->own_stream = true;
     }
     hipStream_t s = h->stream;
+    {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
+    }
     auto fail = [&](int code) { gpx_free(h); return code; };
     if (const char *pe = getenv("GPX_PROFILE")) h->prof.on = (pe[0] == '1');   // covers the kernels of gpx_fit itself
 

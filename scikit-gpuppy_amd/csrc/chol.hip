@@ -12,6 +12,8 @@
 //              broadcast + one barrier per pivot), and
 //   trtri128 : inverts the 128x128 factor by recursive doubling over 16x16 blocks on MFMA, so that
 //              every triangular solve against a diagonal block becomes a GEMM with its inverse.
+#include <algorithm>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -288,10 +290,85 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
     return chol_rec(L, ld, bm, b1, Dinv, diagL, info_dev, s, prof);
 }
 
-int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                Profiler *prof)
+// ------------------------------------------------------------------------------------------------
+// Two-level right-looking Cholesky with look-ahead.
+//   outer panels of CHOL_NBP blocks (1024 columns): the bulk trailing update is one K=1024 SYRK per panel on
+//   the main stream; while it runs, the NEXT panel (already updated by a narrow GEMM issued first) is factored
+//   on a second, high-priority stream -- the latency-bound chain  leaf -> panel TRSM -> in-panel update  (128
+//   columns at a time) overlaps with the MFMA-bound bulk instead of serialising with it.
+// The same outer structure is what the multi-GPU host drives (panel owner factors, RCCL broadcast, everybody
+// updates): see skgpuppy_amd/distributed.py.
+// ------------------------------------------------------------------------------------------------
+constexpr int64_t CHOL_NBP = 8;
+
+// factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
+int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
+                      int *info_dev, hipStream_t s, Profiler *prof)
 {
-    return chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
+    for (int64_t j = B0; j < B1; ++j) {
+        GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
+                                  info_dev, (int)(j * TILE), s, prof));
+        const int64_t rows_below = nblk - (j + 1);
+        if (rows_below <= 0) continue;
+        double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
+        GPX_TRY(launch_gemm_nt(Z, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Z, ld, rows_below * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof));
+        const int64_t cols_rest = B1 - (j + 1);
+        if (cols_rest > 0)                                                  // rest of the panel: C -= Z Z[0:cols]^T
+            GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
+                                   cols_rest * TILE, TILE, -1.0, 1.0, 0, s, prof));
+    }
+    return 0;
+}
+
+int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
+                hipStream_t s_pan, Profiler *prof)
+{
+    if (nblk <= CHOL_NBP || s_pan == nullptr)
+        return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
+                                  : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
+    const int64_t P = (nblk + CHOL_NBP - 1) / CHOL_NBP;
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P);
+    hipEvent_t ev0;
+    GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
+    for (int64_t p = 0; p < P; ++p) {
+        GPX_HIP(hipEventCreateWithFlags(&ev_pf[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_next[p], hipEventDisableTiming));
+    }
+    int rc = 0;
+    auto run = [&]() -> int {
+        GPX_HIP(hipEventRecord(ev0, s));
+        GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
+        GPX_TRY(chol_panel_factor(L, ld, nblk, 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL, info_dev, s_pan, prof));
+        GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
+        for (int64_t p = 0; p < P; ++p) {
+            const int64_t B0 = p * CHOL_NBP, B1 = std::min<int64_t>(B0 + CHOL_NBP, nblk), B2 = std::min<int64_t>(B1 + CHOL_NBP, nblk);
+            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));
+            if (B1 >= nblk) break;
+            const int64_t K = (B1 - B0) * TILE;
+            const double *Pn = L + (B1 * TILE) * ld + B0 * TILE;           // panel p, rows >= B1
+            // (1) narrow update of the NEXT panel's columns first ...
+            GPX_TRY(launch_gemm_nt(Pn, ld, Pn, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (nblk - B1) * TILE, (B2 - B1) * TILE, K,
+                                   -1.0, 1.0, 0, s, prof));
+            GPX_HIP(hipEventRecord(ev_next[p], s));
+            // (2) ... so that its factorisation can start on the panel stream ...
+            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+            GPX_TRY(chol_panel_factor(L, ld, nblk, B1, B2, Dinv, diagL, info_dev, s_pan, prof));
+            GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
+            // (3) ... while the bulk of the trailing matrix is updated here
+            if (B2 < nblk) {
+                const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
+                GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
+                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+            }
+        }
+        return 0;
+    };
+    rc = run();
+    (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
+    (void)hipStreamSynchronize(s);
+    (void)hipEventDestroy(ev0);
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); }
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------------

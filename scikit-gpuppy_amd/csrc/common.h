@@ -67,6 +67,7 @@ struct gpx_handle {
     double w[GPX_MAX_D];
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t s_pan = nullptr;   // high-priority side stream: panel factorisation under look-ahead
 
     double *x = nullptr;        // [n, d] raw inputs
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
@@ -110,7 +111,9 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 
 // recursive blocked algorithms (chol.hip)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, Profiler *prof);
+                hipStream_t s, hipStream_t s_pan, Profiler *prof);
+int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
+                      int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);

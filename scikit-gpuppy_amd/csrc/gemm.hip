@@ -14,15 +14,18 @@
 // k l>>4) are bank-conflict free.  LDS 68 KiB/block -> 2 blocks per CU.
 #include "common.h"
 
-constexpr int BM = 128, BN = 128;
-
-template <bool LOWER>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda,
-                                                            const double *B, long ldb, double *C,
-                                                            long ldc, int K, double alpha, double beta)
+// WM x WN = MFMA tiles per wave (rows x cols); the block tile is (32 WM) x (32 WN) with 2x2 waves.
+// (4,4) -> 128x128, the bulk kernel; (2,2) -> 64x64 and (2,4)/(1,4) -> 64x128 / 32x128 for the short, skinny
+// products on the factorisation's critical path, where a 128-tile grid would leave most of the 256 CUs idle
+// (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
+template <int WM, int WN, bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
+                                                            double *C, long ldc, int K, double alpha, double beta)
 {
-    __shared__ __attribute__((aligned(16))) double As[2][BM * GEMM_LDS_S];
-    __shared__ __attribute__((aligned(16))) double Bs[2][BN * GEMM_LDS_S];
+    constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
+    constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
+    __shared__ __attribute__((aligned(16))) double As[2][BTM * GEMM_LDS_S];
+    __shared__ __attribute__((aligned(16))) double Bs[2][BTN * GEMM_LDS_S];
 
     // Block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD a
     // contiguous chunk of the logical tile order, and walk that order in groups of GM row tiles so that the
@@ -34,15 +37,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         const int orig = blockIdx.y * gx + blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
-        constexpr int GM = 8;
-        const int per_group = GM * gx;
-        const int g = lid / per_group, rem = lid - g * per_group;
-        const int first = g * GM;
-        const int rows = (gy - first) < GM ? (gy - first) : GM;
-        by = first + rem % rows;
-        bx = rem / rows;
+        if (LOWER) {
+            // 1-D grid over the lower-triangular tiles only (row-major within the triangle), so every XCD chunk
+            // carries the same number of tiles: lid -> (by, bx) with by(by+1)/2 <= lid < (by+1)(by+2)/2
+            by = (int)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
+            while (by * (by + 1) / 2 > lid) --by;
+            while ((by + 1) * (by + 2) / 2 <= lid) ++by;
+            bx = lid - by * (by + 1) / 2;
+        } else {
+            constexpr int GM = 8;
+            const int per_group = GM * gx;
+            const int g = lid / per_group, rem = lid - g * per_group;
+            const int first = g * GM;
+            const int rows = (gy - first) < GM ? (gy - first) : GM;
+            by = first + rem % rows;
+            bx = rem / rows;
+        }
     }
-    if (LOWER && bx > by) return;
 
     const int t = threadIdx.x;
     const int lr = t >> 3, lc = t & 7;            // staging: row lr (+32 i), 16-byte column chunk lc
@@ -50,48 +61,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    const double *Ag = A + ((long)by * BM + lr) * lda + 2 * lc;
-    const double *Bg = B + ((long)bx * BN + lr) * ldb + 2 * lc;
+    const double *Ag = A + ((long)by * BTM + lr) * lda + 2 * lc;
+    const double *Bg = B + ((long)bx * BTN + lr) * ldb + 2 * lc;
 
-    v4d acc[4][4];
+    v4d acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    v2d ga[4], gb[4];
+    v2d ga[WM], gb[WN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        ga[i] = *reinterpret_cast<const v2d *>(Ag + (long)(32 * i) * lda);
-        gb[i] = *reinterpret_cast<const v2d *>(Bg + (long)(32 * i) * ldb);
+    for (int i = 0; i < WM; ++i) ga[i] = *reinterpret_cast<const v2d *>(Ag + (long)(32 * i) * lda);
+#pragma unroll
+    for (int i = 0; i < WN; ++i) gb[i] = *reinterpret_cast<const v2d *>(Bg + (long)(32 * i) * ldb);
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        double *pa = &As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+        pa[0] = ga[i].x; pa[1] = ga[i].y;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        double *pa = &As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
+    for (int i = 0; i < WN; ++i) {
         double *pb = &Bs[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-        pa[0] = ga[i].x; pa[1] = ga[i].y;
         pb[0] = gb[i].x; pb[1] = gb[i].y;
     }
     __syncthreads();
 
     const int nk = K / GEMM_BK;
-    const int a_off = (wr * 64 + fr) * GEMM_LDS_S + fq;
-    const int b_off = (wc * 64 + fr) * GEMM_LDS_S + fq;
+    const int a_off = (wr * WTM + fr) * GEMM_LDS_S + fq;
+    const int b_off = (wc * WTN + fr) * GEMM_LDS_S + fq;
 
     // Software pipeline.  Fragments are double buffered in registers (set 0/1) one 4-deep k-slice ahead,
     // the next stage's global tile is fetched at the top of the stage, written to the other LDS buffer
     // after the second slice, and the stage barrier sits BEFORE the last slice's MFMAs so that the first
     // fragments of the next stage are read while those MFMAs run: no LDS or HBM latency is exposed between
     // two MFMA groups, only wave skew at the barrier.
-    double fa[2][4], fb[2][4];
+    double fa[2][WM], fb[2][WN];
 #define GPX_LOAD_FRAGS(SET, BUF, KK)                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                 \
+    _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
         fa[SET][i_] = As[BUF][a_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];                \
-        fb[SET][i_] = Bs[BUF][b_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];                \
-    }
+    _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_)                                  \
+        fb[SET][i_] = Bs[BUF][b_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];
 #define GPX_MMA(SET)                                                                   \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
+        _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
             acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i_], fb[SET][j_], acc[i_][j_], 0, 0, 0);
 
     GPX_LOAD_FRAGS(0, 0, 0)
@@ -102,10 +115,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
             const double *Ak = Ag + (long)(kt + 1) * GEMM_BK;
             const double *Bk = Bg + (long)(kt + 1) * GEMM_BK;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ga[i] = *reinterpret_cast<const v2d *>(Ak + (long)(32 * i) * lda);
-                gb[i] = *reinterpret_cast<const v2d *>(Bk + (long)(32 * i) * ldb);
-            }
+            for (int i = 0; i < WM; ++i) ga[i] = *reinterpret_cast<const v2d *>(Ak + (long)(32 * i) * lda);
+#pragma unroll
+            for (int i = 0; i < WN; ++i) gb[i] = *reinterpret_cast<const v2d *>(Bk + (long)(32 * i) * ldb);
         }
         GPX_LOAD_FRAGS(1, cur, 1)
         GPX_MMA(0)
@@ -115,10 +127,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         __builtin_amdgcn_sched_barrier(0);
         if (has_next) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < WM; ++i) {
                 double *pa = &As[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-                double *pb = &Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
                 pa[0] = ga[i].x; pa[1] = ga[i].y;
+            }
+#pragma unroll
+            for (int i = 0; i < WN; ++i) {
+                double *pb = &Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
                 pb[0] = gb[i].x; pb[1] = gb[i].y;
             }
         }
@@ -134,19 +149,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 #undef GPX_MMA
 
     // epilogue: accumulator register r of tile (i,j) is C[row = fq + 4r][col = fr] of that 16x16 tile
-    double *Cw = C + ((long)by * BM + wr * 64 + fq) * ldc + (long)bx * BN + wc * 64 + fr;
+    double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
     if (beta == 0.0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double *p = &Cw[(long)(i * 16 + 4 * r) * ldc + j * 16];
@@ -155,10 +170,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     }
 }
 
+// tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
+constexpr double SMALL_GRID_TILES = 192.0;
+
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
                    int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof)
 {
-    if (M % BM || N % BN || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
+    if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
         gpx_set_error("launch_gemm_nt: shape/alignment not supported (M=%ld N=%ld K=%ld lda=%ld ldb=%ld)", (long)M,
                       (long)N, (long)K, (long)lda, (long)ldb);
@@ -169,15 +187,31 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: lower_only needs a square C");
         return GPX_ERR_BAD_ARG;
     }
-    dim3 grid((unsigned)(N / BN), (unsigned)(M / BM));
-    double tiles = lower_only ? 0.5 * (double)(M / BM) * (double)(M / BM + 1) : (double)(M / BM) * (double)(N / BN);
-    ProfScope ps(prof, s, GPX_K_GEMM, tiles * 2.0 * BM * BN * (double)K);
-    if (lower_only)
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<true>, grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc,
-                           (int)K, alpha, beta);
-    else
-        hipLaunchKernelGGL(gemm_nt_f64_kernel<false>, grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc,
-                           (int)K, alpha, beta);
+    const double tiles = lower_only ? 0.5 * (double)(M / TILE) * (double)(M / TILE + 1) : (double)(M / TILE) * (double)(N / TILE);
+    ProfScope ps(prof, s, GPX_K_GEMM, tiles * 2.0 * TILE * TILE * (double)K);
+    const bool in_place = (C == A || C == B);   // in-place TRSM leaves: exactly one column tile per row block
+    if (in_place && N != TILE) {
+        gpx_set_error("launch_gemm_nt: in-place product needs N == %d", TILE);
+        return GPX_ERR_BAD_ARG;
+    }
+#define GPX_LAUNCH(WM_, WN_)                                                                                          \
+    do {                                                                                                              \
+        dim3 grid((unsigned)(N / (32 * WN_)), (unsigned)(M / (32 * WM_)));                                            \
+        const unsigned nt_ = (unsigned)(M / (32 * WM_));                                                              \
+        if (lower_only)                                                                                               \
+            hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
+                               (long)ldc, (int)K, alpha, beta);                                                       \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
+                               (long)ldc, (int)K, alpha, beta);                                                       \
+    } while (0)
+    if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
+    else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
+    else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
+        if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);
+        else GPX_LAUNCH(1, 4);
+    } else GPX_LAUNCH(2, 2);
+#undef GPX_LAUNCH
     GPX_HIP(hipGetLastError());
     return 0;
 }
