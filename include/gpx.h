@@ -47,6 +47,7 @@ int         gpx_abi_version(void);
 const char *gpx_last_error(void);                 /* thread-local text of the last failure */
 int         gpx_device_count(void);               /* number of visible HIP devices (0 if none) */
 int         gpx_set_device(int device);           /* device used by subsequently created handles */
+int         gpx_pool_trim(void);                  /* release the device buffers cached by the library's allocator */
 
 /* ---- a1/a2: GaussianCovariance.cov_matrix_ij / cov_matrix  (skgpuppy/Covariance.py:461-483) ----
  * K_out[n1,n2] = v exp(-1/2 sum_k w_k (xi_k - xj_k)^2); add_diag (= vt for cov_matrix, 0 for

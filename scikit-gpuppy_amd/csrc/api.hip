@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <new>
 
 #include "common.h"
@@ -122,11 +124,73 @@ void Profiler::destroy()
 }
 
 // ---- helpers -----------------------------------------------------------------------------------
+// Caching device allocator: a fit + predict cycle allocates and frees the same multi-GB buffers every time;
+// hipMalloc/hipFree of that size cost milliseconds and hipFree synchronises the device.  Freed blocks are
+// kept (exact-size buckets, per device) and handed back to the next request; gpx_pool_trim() releases them.
+namespace {
+struct PoolKey { int dev; size_t bytes; bool operator<(const PoolKey &o) const { return dev != o.dev ? dev < o.dev : bytes < o.bytes; } };
+std::mutex g_pool_mu;
+std::map<PoolKey, std::vector<void *>> g_pool_free;
+std::map<void *, PoolKey> g_pool_live;
+size_t g_pool_cached_bytes = 0;
+}   // namespace
+
 static int dalloc(double **p, int64_t elems)
 {
     *p = nullptr;
     if (elems <= 0) elems = 1;
-    GPX_HIP(hipMalloc((void **)p, sizeof(double) * (size_t)elems));
+    const size_t bytes = ((sizeof(double) * (size_t)elems + 255) / 256) * 256;
+    int dev = 0;
+    GPX_HIP(hipGetDevice(&dev));
+    const PoolKey key{dev, bytes};
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.find(key);
+        if (it != g_pool_free.end() && !it->second.empty()) {
+            void *q = it->second.back();
+            it->second.pop_back();
+            g_pool_cached_bytes -= bytes;
+            g_pool_live[q] = key;
+            *p = (double *)q;
+            return 0;
+        }
+    }
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {   // out of memory: drop the cache and retry once
+        (void)hipGetLastError();
+        gpx_pool_trim();
+        e = hipMalloc(&q, bytes);
+    }
+    if (e != hipSuccess) {
+        gpx_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return GPX_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[q] = key;
+    *p = (double *)q;
+    return 0;
+}
+
+// the caller guarantees that no kernel still uses p (every entry point synchronises its stream before freeing)
+static void dfree(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) { (void)hipFree(p); return; }
+    g_pool_free[it->second].push_back(p);
+    g_pool_cached_bytes += it->second.bytes;
+    g_pool_live.erase(it);
+}
+
+extern "C" int gpx_pool_trim(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : g_pool_free)
+        for (void *q : kv.second) dfree(q);
+    g_pool_free.clear();
+    g_pool_cached_bytes = 0;
     return 0;
 }
 
@@ -154,7 +218,7 @@ static int parse_theta(const double *theta, int d, double *v, double *vt, double
 static int ensure_Z(gpx_handle *h, int64_t rows)
 {
     if (h->zrows >= rows && h->Z) return 0;
-    if (h->Z) { (void)hipFree(h->Z); h->Z = nullptr; h->zrows = 0; }
+    if (h->Z) { dfree(h->Z); h->Z = nullptr; h->zrows = 0; }
     GPX_TRY(dalloc(&h->Z, rows * h->npad));
     h->zrows = rows;
     return 0;
@@ -189,9 +253,9 @@ extern "C" int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_d
     }
     int rc = launch_gram(a, n1, b, n2, d, v, add_diag, lower_only, pad_identity ? 2 : 1, out_dev, ld, rows_pad, cols_pad, s, nullptr);
     hipError_t e = hipStreamSynchronize(s);
-    (void)hipFree(swd);
-    (void)hipFree(a);
-    if (b != a) (void)hipFree(b);
+    dfree(swd);
+    dfree(a);
+    if (b != a) dfree(b);
     if (rc) return rc;
     GPX_HIP(e);
     return 0;
@@ -224,9 +288,9 @@ extern "C" int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t 
             rc = GPX_ERR_HIP;
         }
     } while (0);
-    if (b && b != a) (void)hipFree(b);
-    if (a) (void)hipFree(a);
-    if (out) (void)hipFree(out);
+    if (b && b != a) dfree(b);
+    if (a) dfree(a);
+    if (out) dfree(out);
     return rc;
 }
 
@@ -239,7 +303,7 @@ extern "C" void gpx_free(gpx_handle *h)
     h->prof.destroy();
     double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
     for (double *p : bufs)
-        if (p) (void)hipFree(p);
+        if (p) dfree(p);
     if (h->info_dev) (void)hipFree(h->info_dev);
     if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); (void)hipStreamDestroy(h->s_pan); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -377,7 +441,7 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
     double *xq = nullptr, *xqw = nullptr, *mv = nullptr;
     GPX_TRY(dalloc(&xq, chunk * d));
     int rc = 0;
-    if ((rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) { (void)hipFree(xq); if (xqw) (void)hipFree(xqw); return rc; }
+    if ((rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) { dfree(xq); if (xqw) dfree(xqw); return rc; }
     for (int64_t m0 = 0; m0 < m && rc == 0; m0 += chunk) {
         const int64_t mc = std::min<int64_t>(chunk, m - m0), mp = round_up(mc, TILE);
         hipError_t e = hipMemcpyAsync(xq, xs + m0 * d, sizeof(double) * mc * d, hipMemcpyDefault, s);
@@ -395,9 +459,9 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
         if (e != hipSuccess) { gpx_set_error("predict copy-out failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
     }
     (void)hipStreamSynchronize(s);
-    (void)hipFree(xq);
-    (void)hipFree(xqw);
-    (void)hipFree(mv);
+    dfree(xq);
+    dfree(xqw);
+    dfree(mv);
     return rc;
 }
 
@@ -424,11 +488,11 @@ static int ensure_kinv(gpx_handle *h)
         (rc = trsm_right_lt(h->Z, h->npad, h->npad, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof)) ||
         (rc = launch_gemm_nt(h->Z, h->npad, h->Z, h->npad, K, h->npad, h->npad, h->npad, h->npad, 1.0, 0.0, 1, s, &h->prof)) ||
         (rc = launch_symmetrize_lower(K, h->npad, h->npad, s))) {
-        (void)hipFree(K);
+        dfree(K);
         return rc;
     }
     hipError_t e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(K); gpx_set_error("Kinv build failed: %s", hipGetErrorString(e)); return GPX_ERR_HIP; }
+    if (e != hipSuccess) { dfree(K); gpx_set_error("Kinv build failed: %s", hipGetErrorString(e)); return GPX_ERR_HIP; }
     h->Kinv = K;
     return 0;
 }
@@ -454,7 +518,7 @@ extern "C" int gpx_chol(gpx_handle *h, double *L_out)
                        (long)h->npad, (long)h->n, tmp, (long)h->n);
     hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * h->n * h->n, hipMemcpyDefault, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(tmp);
+    dfree(tmp);
     GPX_HIP(e);
     return 0;
 }
@@ -510,7 +574,7 @@ extern "C" int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, dou
     double *ud = nullptr, *buf = nullptr;
     GPX_TRY(dalloc(&ud, d));
     int rc = dalloc(&buf, n * (1 + d + (int64_t)d * d));
-    if (rc) { (void)hipFree(ud); return rc; }
+    if (rc) { dfree(ud); return rc; }
     hipError_t e = hipMemcpy(ud, u, sizeof(double) * d, hipMemcpyDefault);
     double *Cd = buf, *Jd = buf + n, *Hd = Jd + n * d;
     if (e == hipSuccess) {
@@ -520,8 +584,8 @@ extern "C" int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, dou
         if (!rc && e == hipSuccess && H) e = hipMemcpyAsync(H, Hd, sizeof(double) * n * d * d, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    (void)hipFree(ud);
-    (void)hipFree(buf);
+    dfree(ud);
+    dfree(buf);
     if (rc) return rc;
     GPX_HIP(e);
     return 0;
@@ -663,7 +727,7 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     hipError_t er = hipMemcpyAsync(Lsd, Ls.data(), sizeof(double) * d * d, hipMemcpyHostToDevice, s);
     if (er == hipSuccess) er = hipMemcpyAsync(ddd, dd.data(), sizeof(double) * d, hipMemcpyHostToDevice, s);
     if (er == hipSuccess) er = hipMemcpyAsync(ud, uh, sizeof(double) * d, hipMemcpyHostToDevice, s);
-    if (er != hipSuccess) { (void)hipFree(buf); gpx_set_error("exact: constant upload failed"); return GPX_ERR_HIP; }
+    if (er != hipSuccess) { dfree(buf); gpx_set_error("exact: constant upload failed"); return GPX_ERR_HIP; }
     rc = launch_exact_build(h->x, h->n, np, d, ud, h->wdev, Lsd, ddd, h->v, h->vt, nc1, aT, bT, e, F, lm, s);
     std::vector<std::pair<const double *, const double *>> pr;
     pr.push_back({h->alpha, lm});
@@ -675,7 +739,7 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
         if (er == hipSuccess) er = hipStreamSynchronize(s);
         if (er != hipSuccess) { gpx_set_error("exact: %s", hipGetErrorString(er)); rc = GPX_ERR_HIP; }
     } else (void)hipStreamSynchronize(s);
-    (void)hipFree(buf);
+    dfree(buf);
     if (rc) return rc;
     const double mu = o[0];
     if (mean) *mean = mu;

@@ -111,19 +111,23 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, doubl
 // double the block size with  X21 = -X22 (L21 X11)  on MFMA 16x16x4 tiles.  The intermediate
 // T = L21 X11 is parked in X21's own (still unused) LDS slot.
 // ------------------------------------------------------------------------------------------------
-constexpr int XS = 130;   // LDS row stride in doubles (XS/2 odd -> conflict-free fragment reads)
+// LDS image: the 36 lower-triangular 16x16 blocks only, each padded to 16x17 doubles (odd stride ->
+// conflict-free fragment reads): 78 KB, so the kernel fits on a CU next to a bulk GEMM workgroup instead of
+// waiting for a completely empty CU while the trailing update runs on the other stream.
+constexpr int XB = 16 * 17;                                  // doubles per packed block
+__device__ __forceinline__ int xblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * XB; }
 
 __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld, double *dinv)
 {
-    __shared__ __attribute__((aligned(16))) double X[TILE * XS];
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int fr = lane & 15, fq = lane >> 4;
 
-    // stage L's diagonal 16x16 blocks, zero everything else
-    for (int e = t; e < TILE * TILE; e += 256) {
-        const int i = e >> 7, k = e & 127;
-        X[i * XS + k] = ((i >> 4) == (k >> 4) && k <= i) ? L[(long)i * ld + k] : 0.0;
+    // stage L's eight diagonal 16x16 blocks (zeros above the diagonal)
+    for (int e = t; e < 8 * 256; e += 256) {
+        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        X[xblk(b, b) + r * 17 + c] = (c <= r) ? L[(long)(16 * b + r) * ld + 16 * b + c] : 0.0;
     }
     __syncthreads();
 
@@ -131,21 +135,21 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
     double xcol[16];
     if (t < 128) {
         const int b = t >> 4, c = t & 15;
-        const double *Lb = &X[(16 * b) * XS + 16 * b];
+        const double *Lb = &X[xblk(b, b)];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             double s = (i == c) ? 1.0 : 0.0;
 #pragma unroll
-            for (int k = 0; k < i; ++k) s = fma(-Lb[i * XS + k], xcol[k], s);
-            xcol[i] = s / Lb[i * XS + i];
+            for (int k = 0; k < i; ++k) s = fma(-Lb[i * 17 + k], xcol[k], s);
+            xcol[i] = s / Lb[i * 17 + i];
         }
     }
     __syncthreads();
     if (t < 128) {
         const int b = t >> 4, c = t & 15;
-        double *Xb = &X[(16 * b) * XS + 16 * b];
+        double *Xb = &X[xblk(b, b)];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Xb[i * XS + c] = xcol[i];   // zero for i < c
+        for (int i = 0; i < 16; ++i) Xb[i * 17 + c] = xcol[i];   // zero for i < c
     }
     __syncthreads();
 
@@ -161,28 +165,28 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
             res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
             if (task < ntask) {
                 const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int r0 = 16 * (2 * s * p + s + i);      // first row of block row i of X21 / L21
-                const int c0 = 16 * (2 * s * p);              // first col of X11
+                const int rb = 2 * s * p + s + i;             // block row of X21 / L21
+                const int cb = 2 * s * p;                     // first block col of X11
                 v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
                 for (int k = j; k < s; ++k) {
-                    const double *Lg = L + (long)(r0 + fr) * ld + c0 + 16 * k + fq;       // A[row fr][4kk + fq]
-                    const double *Xk = &X[(c0 + 16 * k + fq) * XS + c0 + 16 * j + fr];    // B[4kk + fq][col fr]
+                    const double *Lg = L + (long)(16 * rb + fr) * ld + 16 * (cb + k) + fq;   // A[row fr][4kk + fq]
+                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // B[4kk + fq][col fr]
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[4 * kk], Xk[4 * kk * XS], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
                 }
                 res[q] = acc;
             }
         }
-        // nobody reads X21's region in phase A, so T can be stored without a barrier in between
+        // nobody reads X21's blocks in phase A, so T can be stored without a barrier in between
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int task = wave + 4 * q;
             if (task < ntask) {
                 const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int r0 = 16 * (2 * s * p + s + i), c0 = 16 * (2 * s * p + j);
+                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) X[(r0 + fq + 4 * r) * XS + c0 + fr] = res[q][r];
+                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
             }
         }
         __syncthreads();
@@ -192,15 +196,15 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
             const int task = wave + 4 * q;
             if (task < ntask) {
                 const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 16 * (2 * s * p + s);          // first row/col of X22 (= first row of X21 / T)
-                const int cb = 16 * (2 * s * p);              // first col of X21 / T
+                const int rb = 2 * s * p + s;                 // first block row/col of X22 (= first block row of X21 / T)
+                const int cb = 2 * s * p;                     // first block col of X21 / T
                 v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
                 for (int k = 0; k <= i; ++k) {
-                    const double *Xa = &X[(rb + 16 * i + fr) * XS + rb + 16 * k + fq];    // X22[i][k]: A[row fr][4kk + fq]
-                    const double *Tk = &X[(rb + 16 * k + fq) * XS + cb + 16 * j + fr];    // T[k][j]:  B[4kk + fq][col fr]
+                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];              // X22[i][k]: A[row fr][4kk + fq]
+                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];              // T[k][j]:  B[4kk + fq][col fr]
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * XS], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
                 }
                 res[q] = acc;
             }
@@ -211,9 +215,9 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
             const int task = wave + 4 * q;
             if (task < ntask) {
                 const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int r0 = 16 * (2 * s * p + s + i), c0 = 16 * (2 * s * p + j);
+                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) X[(r0 + fq + 4 * r) * XS + c0 + fr] = -res[q][r];
+                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
             }
         }
         __syncthreads();
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
 
     for (int e = t; e < TILE * TILE; e += 256) {
         const int i = e >> 7, k = e & 127;
-        dinv[e] = X[i * XS + k];
+        dinv[e] = ((k >> 4) <= (i >> 4)) ? X[xblk(i >> 4, k >> 4) + (i & 15) * 17 + (k & 15)] : 0.0;
     }
 }
 
@@ -302,9 +306,12 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
 constexpr int64_t CHOL_NBP = 8;
 
 // factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
-int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
+int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof)
 {
+    // (a) the (B1-B0)-block diagonal square, 128 columns at a time: only this latency-bound chain of small
+    //     kernels is serial; (b) everything below it in ONE recursive TRSM made of large GEMMs.
+    const int64_t nblk = B1;
     for (int64_t j = B0; j < B1; ++j) {
         GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
                                   info_dev, (int)(j * TILE), s, prof));
@@ -317,6 +324,8 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B
             GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
                                    cols_rest * TILE, TILE, -1.0, 1.0, 0, s, prof));
     }
+    if (nblk_all > B1)
+        GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk_all - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
     return 0;
 }
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "gpx_last_error": (ctypes.c_char_p, []),
     "gpx_device_count": (_int, []),
     "gpx_set_device": (_int, [_int]),
+    "gpx_pool_trim": (_int, []),
     "gpx_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _dp]),
     "gpx_fit": (_int, [_dp, _dp, _i64, _int, _dp, ctypes.c_void_p, ctypes.POINTER(_hp)]),
     "gpx_free": (None, [_hp]),
