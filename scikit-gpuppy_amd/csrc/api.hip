@@ -306,6 +306,7 @@ extern "C" void gpx_free(gpx_handle *h)
         if (p) dfree(p);
     if (h->info_dev) (void)hipFree(h->info_dev);
     if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); (void)hipStreamDestroy(h->s_pan); }
+    if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -315,7 +316,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -344,9 +345,35 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
     }
     hipStream_t s = h->stream;
     {
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
+        // Look-ahead streams.  The diagonal chain of the next panel must not fight the MFMA-saturating bulk
+        // update for issue slots (it runs 3-4x slower when it does), so a few CUs are reserved for it with CU
+        // masks: GPX_RESERVED_CUS (spread over the XCDs; default 0 = use a high-priority stream instead) for the side stream, the rest for the bulk.
+        int ncu = 0;
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+        int reserve = 0;   // CU masks measured slower on ROCm 7.2 (the unmasked stream's dispatches slow down): off by default
+        if (const char *e = getenv("GPX_RESERVED_CUS")) reserve = atoi(e);
+        bool masked = false;
+        if (ncu >= 64 && reserve > 0 && reserve < ncu / 2) {
+            const int words = (ncu + 31) / 32;
+            std::vector<uint32_t> m_side(words, 0u), m_bulk(words, 0u);
+            for (int c = 0; c < ncu; ++c) {
+                if (c < reserve) m_side[c >> 5] |= 1u << (c & 31);
+                else m_bulk[c >> 5] |= 1u << (c & 31);
+            }
+            if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
+                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess)
+                masked = true;
+            else {
+                (void)hipGetLastError();
+                if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
+                h->s_bulk = nullptr;
+            }
+        }
+        if (!masked) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
+        }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };
     if (const char *pe = getenv("GPX_PROFILE")) h->prof.on = (pe[0] == '1');   // covers the kernels of gpx_fit itself

@@ -330,53 +330,68 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, Profiler *prof)
+                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr)
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                   : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
     const int64_t P = (nblk + CHOL_NBP - 1) / CHOL_NBP;
-    std::vector<hipEvent_t> ev_pf(P), ev_next(P);
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P);
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
     for (int64_t p = 0; p < P; ++p) {
         GPX_HIP(hipEventCreateWithFlags(&ev_pf[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_next[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_bulk[p], hipEventDisableTiming));
     }
+    if (!s_bulk) s_bulk = s;
     int rc = 0;
     auto run = [&]() -> int {
+        // Per outer panel p the main stream runs, in order:
+        //   tall TRSM of panel p (rows below its diagonal square; large GEMMs, whole machine)
+        //   narrow update of panel p+1's columns               -> event: the side stream may start
+        //   bulk SYRK of everything right of panel p+1
+        // and the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, a few
+        // CUs, pure latency) underneath the bulk SYRK.
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
-        GPX_TRY(chol_panel_factor(L, ld, nblk, 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL, info_dev, s_pan, prof));
+        GPX_TRY(chol_panel_factor(L, ld, std::min<int64_t>(CHOL_NBP, nblk), 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL,
+                                  info_dev, s_pan, prof));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = p * CHOL_NBP, B1 = std::min<int64_t>(B0 + CHOL_NBP, nblk), B2 = std::min<int64_t>(B1 + CHOL_NBP, nblk);
-            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));
+            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) break;
+            GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const int64_t K = (B1 - B0) * TILE;
             const double *Pn = L + (B1 * TILE) * ld + B0 * TILE;           // panel p, rows >= B1
-            // (1) narrow update of the NEXT panel's columns first ...
             GPX_TRY(launch_gemm_nt(Pn, ld, Pn, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (nblk - B1) * TILE, (B2 - B1) * TILE, K,
                                    -1.0, 1.0, 0, s, prof));
             GPX_HIP(hipEventRecord(ev_next[p], s));
-            // (2) ... so that its factorisation can start on the panel stream ...
-            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_panel_factor(L, ld, nblk, B1, B2, Dinv, diagL, info_dev, s_pan, prof));
-            GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
-            // (3) ... while the bulk of the trailing matrix is updated here
+            // bulk SYRK first in host order (its launch must not queue behind the ~30 small launches below);
+            // it runs on the bulk stream, whose CU mask leaves a few CUs to the side stream
             if (B2 < nblk) {
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
+                if (s_bulk != s) GPX_HIP(hipStreamWaitEvent(s_bulk, ev_next[p], 0));
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
-                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s_bulk, prof));
+                if (s_bulk != s) {
+                    GPX_HIP(hipEventRecord(ev_bulk[p], s_bulk));
+                    GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
+                }
             }
+            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+            GPX_TRY(chol_panel_factor(L, ld, B2, B1, B2, Dinv, diagL, info_dev, s_pan, prof));   // diagonal square only
+            GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
         return 0;
     };
     rc = run();
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
+    if (s_bulk != s) (void)hipStreamSynchronize(s_bulk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
-    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); }
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_bulk[p]); }
     return rc;
 }
 

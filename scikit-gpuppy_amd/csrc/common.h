@@ -67,7 +67,8 @@ struct gpx_handle {
     double w[GPX_MAX_D];
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t s_pan = nullptr;   // high-priority side stream: panel factorisation under look-ahead
+    hipStream_t s_pan = nullptr;   // side stream for the latency-bound diagonal chain (CU-masked: a few reserved CUs)
+    hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
 
     double *x = nullptr;        // [n, d] raw inputs
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
@@ -111,7 +112,7 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 
 // recursive blocked algorithms (chol.hip)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, hipStream_t s_pan, Profiler *prof);
+                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)

@@ -12,16 +12,39 @@
 // barrier per stage; global loads are 16 B/lane with 8 lanes covering one 128-B row segment; LDS
 // rows are padded to an odd stride (17 doubles) so the ds_read2_b64 fragment reads (lane l -> row l&15,
 // k l>>4) are bank-conflict free.  LDS 68 KiB/block -> 2 blocks per CU.
+#include <stdlib.h>
+
 #include "common.h"
+
+// MFMA issue.  For the 32-accumulator (128x256) tile the accumulators must live in AGPRs; hipcc 7.2 then copies
+// them VGPR<->AGPR around every builtin MFMA (and spills), so that variant issues the instruction through inline
+// asm with the accumulator pinned to the AGPR class ("+a").  Hazards the assembler would otherwise pad are
+// covered by construction: operands come from LDS reads (waitcnt by the compiler), an accumulator is reused
+// only after 31 other MFMAs, and gpx_acc_fence() separates the last MFMA from the first accumulator read.
+#ifdef GPX_GEMM_STAMP
+__device__ unsigned long long gpx_stamp_sink[5];
+#endif
+
+template <bool ASM>
+__device__ __forceinline__ void gpx_mma(v4d &acc, double a, double b)
+{
+    if constexpr (ASM) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void gpx_acc_fence(v4d &a0, v4d &a1, v4d &a2, v4d &a3, v4d &a4, v4d &a5, v4d &a6, v4d &a7)
+{
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5), "+a"(a6), "+a"(a7));
+}
 
 // WM x WN = MFMA tiles per wave (rows x cols); the block tile is (32 WM) x (32 WN) with 2x2 waves.
 // (4,4) -> 128x128, the bulk kernel; (2,2) -> 64x64 and (2,4)/(1,4) -> 64x128 / 32x128 for the short, skinny
 // products on the factorisation's critical path, where a 128-tile grid would leave most of the 256 CUs idle
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 template <int WM, int WN, bool LOWER>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
+__global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
                                                             double *C, long ldc, int K, double alpha, double beta)
 {
+    constexpr bool BIG = (WM * WN > 16);          // 32 accumulators: AGPR-pinned inline-asm MFMA path
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
     __shared__ __attribute__((aligned(16))) double As[2][BTM * GEMM_LDS_S];
@@ -70,32 +93,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    v2d ga[WM], gb[WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i) ga[i] = *reinterpret_cast<const v2d *>(Ag + (long)(32 * i) * lda);
-#pragma unroll
-    for (int i = 0; i < WN; ++i) gb[i] = *reinterpret_cast<const v2d *>(Bg + (long)(32 * i) * ldb);
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        double *pa = &As[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-        pa[0] = ga[i].x; pa[1] = ga[i].y;
+    // global staging registers, two sets: the tile of stage t+2 is in flight while stage t computes
+    v2d ga[2][WM], gb[2][WN];
+    const int nk = K / GEMM_BK;
+#define GPX_GLOAD(SET, KT)                                                                             \
+    {                                                                                                  \
+        const double *Ak_ = Ag + (long)(KT) * GEMM_BK;                                                 \
+        const double *Bk_ = Bg + (long)(KT) * GEMM_BK;                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                              \
+            ga[SET][i_] = *reinterpret_cast<const v2d *>(Ak_ + (long)(32 * i_) * lda);                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_)                                              \
+            gb[SET][i_] = *reinterpret_cast<const v2d *>(Bk_ + (long)(32 * i_) * ldb);                 \
     }
-#pragma unroll
-    for (int i = 0; i < WN; ++i) {
-        double *pb = &Bs[0][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-        pb[0] = gb[i].x; pb[1] = gb[i].y;
+#define GPX_LSTORE(SET, BUF)                                                                           \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_) {                                            \
+            double *pa_ = &As[BUF][(lr + 32 * i_) * GEMM_LDS_S + 2 * lc];                              \
+            pa_[0] = ga[SET][i_].x; pa_[1] = ga[SET][i_].y;                                            \
+        }                                                                                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_) {                                            \
+            double *pb_ = &Bs[BUF][(lr + 32 * i_) * GEMM_LDS_S + 2 * lc];                              \
+            pb_[0] = gb[SET][i_].x; pb_[1] = gb[SET][i_].y;                                            \
+        }                                                                                              \
     }
+    GPX_GLOAD(0, 0)
+    if (nk > 1) GPX_GLOAD(1, 1)
+    GPX_LSTORE(0, 0)
     __syncthreads();
 
-    const int nk = K / GEMM_BK;
     const int a_off = (wr * WTM + fr) * GEMM_LDS_S + fq;
     const int b_off = (wc * WTN + fr) * GEMM_LDS_S + fq;
 
-    // Software pipeline.  Fragments are double buffered in registers (set 0/1) one 4-deep k-slice ahead,
-    // the next stage's global tile is fetched at the top of the stage, written to the other LDS buffer
-    // after the second slice, and the stage barrier sits BEFORE the last slice's MFMAs so that the first
-    // fragments of the next stage are read while those MFMAs run: no LDS or HBM latency is exposed between
-    // two MFMA groups, only wave skew at the barrier.
+    // Software pipeline.  Per 16-deep stage t (LDS buffer t&1):
+    //   top      : global loads of stage t+2 -> staging set t&1     (1.5 stages of HBM/L2 latency cover)
+    //   slices   : fragments double buffered in registers one 4-deep k-slice ahead of the MFMAs
+    //   mid      : staging set (t+1)&1 (loaded during stage t-1) -> the other LDS buffer
+    //   barrier  : BEFORE the last slice's MFMAs, so the first fragments of stage t+1 are read while they run
     double fa[2][WM], fb[2][WN];
 #define GPX_LOAD_FRAGS(SET, BUF, KK)                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
@@ -105,49 +138,52 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 #define GPX_MMA(SET)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
         _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
-            acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i_], fb[SET][j_], acc[i_][j_], 0, 0, 0);
+            gpx_mma<BIG>(acc[i_][j_], fa[SET][i_], fb[SET][j_]);
+#define GPX_STAGE(CUR, KT)                                                             \
+    {                                                                                  \
+        if ((KT) + 2 < nk) GPX_GLOAD(CUR, (KT) + 2)                                    \
+        GPX_LOAD_FRAGS(1, CUR, 1)                                                      \
+        GPX_MMA(0)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        GPX_LOAD_FRAGS(0, CUR, 2)                                                      \
+        GPX_MMA(1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        if ((KT) + 1 < nk) GPX_LSTORE(1 - (CUR), 1 - (CUR))                            \
+        GPX_LOAD_FRAGS(1, CUR, 3)                                                      \
+        GPX_MMA(0)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        __syncthreads();                                                               \
+        if ((KT) + 1 < nk) { GPX_LOAD_FRAGS(0, 1 - (CUR), 0) }                         \
+        GPX_MMA(1)                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+    }
 
     GPX_LOAD_FRAGS(0, 0, 0)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1, nxt = cur ^ 1;
-        const bool has_next = kt + 1 < nk;
-        if (has_next) {
-            const double *Ak = Ag + (long)(kt + 1) * GEMM_BK;
-            const double *Bk = Bg + (long)(kt + 1) * GEMM_BK;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) ga[i] = *reinterpret_cast<const v2d *>(Ak + (long)(32 * i) * lda);
-#pragma unroll
-            for (int i = 0; i < WN; ++i) gb[i] = *reinterpret_cast<const v2d *>(Bk + (long)(32 * i) * ldb);
-        }
-        GPX_LOAD_FRAGS(1, cur, 1)
-        GPX_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        GPX_LOAD_FRAGS(0, cur, 2)
-        GPX_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                double *pa = &As[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-                pa[0] = ga[i].x; pa[1] = ga[i].y;
-            }
-#pragma unroll
-            for (int i = 0; i < WN; ++i) {
-                double *pb = &Bs[nxt][(lr + 32 * i) * GEMM_LDS_S + 2 * lc];
-                pb[0] = gb[i].x; pb[1] = gb[i].y;
-            }
-        }
-        GPX_LOAD_FRAGS(1, cur, 3)
-        GPX_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (has_next) { GPX_LOAD_FRAGS(0, nxt, 0) }
-        GPX_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
+    for (int kt = 0; kt < nk; kt += 2) {
+        GPX_STAGE(0, kt)
+        if (kt + 1 < nk) GPX_STAGE(1, kt + 1)
     }
+#undef GPX_STAGE
+#undef GPX_GLOAD
+#undef GPX_LSTORE
 #undef GPX_LOAD_FRAGS
 #undef GPX_MMA
+#ifdef GPX_GEMM_STAMP
+    if (lane == 0)   // stamp sums leave through a buffer of their own that no kernel reads
+        for (int q = 0; q < 5; ++q) atomicAdd(&gpx_stamp_sink[q], st_acc[q]);
+#endif
 
+    if constexpr (BIG) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            static_assert(!BIG || WN == 8 || WM == 8, "fence helper takes 8 accumulators at a time");
+            if constexpr (WN == 8) gpx_acc_fence(acc[i][0], acc[i][1], acc[i][2], acc[i][3], acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+        }
+        if constexpr (WM == 8 && WN != 8) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) gpx_acc_fence(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
+        }
+    }
     // epilogue: accumulator register r of tile (i,j) is C[row = fq + 4r][col = fr] of that 16x16 tile
     double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
     if (beta == 0.0) {
@@ -169,6 +205,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
                 }
     }
 }
+
+#ifdef GPX_GEMM_STAMP
+extern "C" int gpx_stamp_read(unsigned long long *out)
+{
+    GPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx_stamp_sink), sizeof(unsigned long long) * 5));
+    unsigned long long z[5] = {0, 0, 0, 0, 0};
+    GPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gpx_stamp_sink), z, sizeof(z)));
+    return 0;
+}
+#endif
 
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
 constexpr double SMALL_GRID_TILES = 192.0;
@@ -205,7 +251,10 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
                                (long)ldc, (int)K, alpha, beta);                                                       \
     } while (0)
-    if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
+    static const int big_mode = getenv("GPX_GEMM_BIG") ? atoi(getenv("GPX_GEMM_BIG")) : 0;
+    if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 1 && N % 256 == 0) GPX_LAUNCH(4, 8);
+    else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 2 && M % 256 == 0) GPX_LAUNCH(8, 4);
+    else if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);

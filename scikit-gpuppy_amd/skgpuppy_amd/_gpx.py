@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpx.so")
+LIB_PATH = os.environ.get("GPX_LIB", os.path.join(_HERE, "libgpx.so"))   # GPX_LIB: diagnostic builds only
 
 GPX_ERR_BAD_ARG, GPX_ERR_HIP, GPX_ERR_NO_DEVICE, GPX_ERR_STATE = -1, -2, -3, -4
 K_GRAM, K_GEMM, K_POTRF_LEAF, K_TRSV, K_REDUCE, K_QUAD, K_EXACT = range(7)
