@@ -47,12 +47,15 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     constexpr bool BIG = (WM * WN > 16);          // 32 accumulators: AGPR-pinned inline-asm MFMA path
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
-    __shared__ __attribute__((aligned(16))) double As[2][BTM * GEMM_LDS_S];
-    __shared__ __attribute__((aligned(16))) double Bs[2][BTN * GEMM_LDS_S];
+    // ONE LDS array: per stage an A image [BTM][16] and a B image [BTN][16] of doubles (128-byte rows, no padding),
+    // filled by LDS-DMA (global_load_lds, 16 B per lane, 1 KiB = 8 rows per wave-instruction).  The DMA writes
+    // linearly, so the bank-conflict fix is an XOR swizzle of the 16-byte granule index with (row>>1)&7 applied on
+    // the SOURCE address and again on the fragment reads: the 32 lanes of a ds_read_b64 half then hit 32
+    // distinct 8-byte slots of the 256-byte bank row.
+    constexpr int STAGE = (BTM + BTN) * 16;
+    constexpr int NBUF = BIG ? 3 : 2;             // BIG: one workgroup per CU -> room for a third buffer, DMA two stages ahead
+    __shared__ __attribute__((aligned(1024))) double smem[NBUF * STAGE];
 
-    // Block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD a
-    // contiguous chunk of the logical tile order, and walk that order in groups of GM row tiles so that the
-    // tiles resident on one XCD share A row panels and B column panels in its L2 (speed only, never correctness).
     int bx, by;   // bx: column tile, by: row tile
     {
         const int gx = gridDim.x, gy = gridDim.y;
@@ -68,6 +71,7 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             while ((by + 1) * (by + 2) / 2 <= lid) ++by;
             bx = lid - by * (by + 1) / 2;
         } else {
+            // XCD-aware order: contiguous chunk of the logical tile order per XCD, walked in groups of GM row tiles
             constexpr int GM = 8;
             const int per_group = GM * gx;
             const int g = lid / per_group, rem = lid - g * per_group;
@@ -79,13 +83,42 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     }
 
     const int t = threadIdx.x;
-    const int lr = t >> 3, lc = t & 7;            // staging: row lr (+32 i), 16-byte column chunk lc
-    const int wave = t >> 6, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int wr = wave >> 1, wc = wave & 1;
     const int fr = lane & 15, fq = lane >> 4;
 
-    const double *Ag = A + ((long)by * BTM + lr) * lda + 2 * lc;
-    const double *Bg = B + ((long)bx * BTN + lr) * ldb + 2 * lc;
+    // ---- LDS-DMA staging: instruction j of a tile covers rows 8j..8j+7; lane -> (row 8j + lane>>3, granule lane&7)
+    const int drow = lane >> 3;
+    const double *Ag[(BTM / 8 + 3) / 4], *Bg[(BTN / 8 + 3) / 4];
+#pragma unroll
+    for (int u = 0; u < (BTM / 8 + 3) / 4; ++u) {
+        const int j = wave + 4 * u, row = 8 * j + drow;
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        Ag[u] = A + ((long)by * BTM + row) * lda + 2 * c;
+    }
+#pragma unroll
+    for (int u = 0; u < (BTN / 8 + 3) / 4; ++u) {
+        const int j = wave + 4 * u, row = 8 * j + drow;
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        Bg[u] = B + ((long)bx * BTN + row) * ldb + 2 * c;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+#define GPX_DMA_STAGE(BUF, KT)                                                                                      \
+    {                                                                                                               \
+        _Pragma("unroll") for (int u_ = 0; u_ < (BTM / 8 + 3) / 4; ++u_) {                                          \
+            const int j_ = wave + 4 * u_;                                                                           \
+            if (BTM / 8 % 4 == 0 || j_ < BTM / 8)                                                                   \
+                __builtin_amdgcn_global_load_lds((glb_void *)(Ag[u_] + (long)(KT) * GEMM_BK),                       \
+                                                 (lds_void *)(smem + (BUF) * STAGE + j_ * 128), 16, 0, 0);          \
+        }                                                                                                           \
+        _Pragma("unroll") for (int u_ = 0; u_ < (BTN / 8 + 3) / 4; ++u_) {                                          \
+            const int j_ = wave + 4 * u_;                                                                           \
+            if (BTN / 8 % 4 == 0 || j_ < BTN / 8)                                                                   \
+                __builtin_amdgcn_global_load_lds((glb_void *)(Bg[u_] + (long)(KT) * GEMM_BK),                       \
+                                                 (lds_void *)(smem + (BUF) * STAGE + BTM * 16 + j_ * 128), 16, 0, 0); \
+        }                                                                                                           \
+    }
 
     v4d acc[WM][WN];
 #pragma unroll
@@ -93,85 +126,82 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    // global staging registers, two sets: the tile of stage t+2 is in flight while stage t computes
-    v2d ga[2][WM], gb[2][WN];
     const int nk = K / GEMM_BK;
-#define GPX_GLOAD(SET, KT)                                                                             \
-    {                                                                                                  \
-        const double *Ak_ = Ag + (long)(KT) * GEMM_BK;                                                 \
-        const double *Bk_ = Bg + (long)(KT) * GEMM_BK;                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                              \
-            ga[SET][i_] = *reinterpret_cast<const v2d *>(Ak_ + (long)(32 * i_) * lda);                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_)                                              \
-            gb[SET][i_] = *reinterpret_cast<const v2d *>(Bk_ + (long)(32 * i_) * ldb);                 \
+    constexpr int NDMA = (BTM / 8 + 3) / 4 + (BTN / 8 + 3) / 4;   // LDS-DMA instructions per wave per stage
+    GPX_DMA_STAGE(0, 0)
+    if constexpr (BIG) {
+        if (nk > 1) GPX_DMA_STAGE(1, 1)
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();   // (hipcc drains the DMA with vmcnt(0) before the barrier)
     }
-#define GPX_LSTORE(SET, BUF)                                                                           \
-    {                                                                                                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_) {                                            \
-            double *pa_ = &As[BUF][(lr + 32 * i_) * GEMM_LDS_S + 2 * lc];                              \
-            pa_[0] = ga[SET][i_].x; pa_[1] = ga[SET][i_].y;                                            \
-        }                                                                                              \
-        _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_) {                                            \
-            double *pb_ = &Bs[BUF][(lr + 32 * i_) * GEMM_LDS_S + 2 * lc];                              \
-            pb_[0] = gb[SET][i_].x; pb_[1] = gb[SET][i_].y;                                            \
-        }                                                                                              \
-    }
-    GPX_GLOAD(0, 0)
-    if (nk > 1) GPX_GLOAD(1, 1)
-    GPX_LSTORE(0, 0)
-    __syncthreads();
 
-    const int a_off = (wr * WTM + fr) * GEMM_LDS_S + fq;
-    const int b_off = (wc * WTN + fr) * GEMM_LDS_S + fq;
+    // fragment addresses: row-local swizzle term depends on the lane only ((row>>1)&7 == (fr>>1)&7 because the
+    // wave/tile row offsets are multiples of 16)
+    const int sw = (fr >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koff[kk] = (((2 * kk + (fq >> 1)) ^ sw) << 1) + (fq & 1);
+    const int a_row = (wr * WTM + fr) * 16;
+    const int b_row = BTM * 16 + (wc * WTN + fr) * 16;
 
-    // Software pipeline.  Per 16-deep stage t (LDS buffer t&1):
-    //   top      : global loads of stage t+2 -> staging set t&1     (1.5 stages of HBM/L2 latency cover)
+    // Software pipeline.  Per 16-deep stage t:
+    //   top      : LDS-DMA of a later stage into a free buffer (no VGPR staging, no ds_write pass)
+    //              2 buffers: stage t+1;  3 buffers (BIG): stage t+2, drained with a COUNTED vmcnt so one stage
+    //              of loads stays in flight across the barrier
     //   slices   : fragments double buffered in registers one 4-deep k-slice ahead of the MFMAs
-    //   mid      : staging set (t+1)&1 (loaded during stage t-1) -> the other LDS buffer
     //   barrier  : BEFORE the last slice's MFMAs, so the first fragments of stage t+1 are read while they run
     double fa[2][WM], fb[2][WN];
-#define GPX_LOAD_FRAGS(SET, BUF, KK)                                                   \
+#define GPX_LOAD_FRAGS(SET, BUFOFF, KK)                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
-        fa[SET][i_] = As[BUF][a_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];                \
+        fa[SET][i_] = smem[(BUFOFF) + a_row + i_ * 256 + koff[KK]];                    \
     _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_)                                  \
-        fb[SET][i_] = Bs[BUF][b_off + i_ * 16 * GEMM_LDS_S + (KK) * 4];
+        fb[SET][i_] = smem[(BUFOFF) + b_row + i_ * 256 + koff[KK]];
 #define GPX_MMA(SET)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
         _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
             gpx_mma<BIG>(acc[i_][j_], fa[SET][i_], fb[SET][j_]);
-#define GPX_STAGE(CUR, KT)                                                             \
-    {                                                                                  \
-        if ((KT) + 2 < nk) GPX_GLOAD(CUR, (KT) + 2)                                    \
-        GPX_LOAD_FRAGS(1, CUR, 1)                                                      \
-        GPX_MMA(0)                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-        GPX_LOAD_FRAGS(0, CUR, 2)                                                      \
-        GPX_MMA(1)                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-        if ((KT) + 1 < nk) GPX_LSTORE(1 - (CUR), 1 - (CUR))                            \
-        GPX_LOAD_FRAGS(1, CUR, 3)                                                      \
-        GPX_MMA(0)                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-        __syncthreads();                                                               \
-        if ((KT) + 1 < nk) { GPX_LOAD_FRAGS(0, 1 - (CUR), 0) }                         \
-        GPX_MMA(1)                                                                     \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-    }
 
     GPX_LOAD_FRAGS(0, 0, 0)
-    for (int kt = 0; kt < nk; kt += 2) {
-        GPX_STAGE(0, kt)
-        if (kt + 1 < nk) GPX_STAGE(1, kt + 1)
+    int cur = 0;                                   // buffer index of stage kt
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
+        const int cur_off = cur * STAGE, nxt_off = nxt * STAGE;
+        const bool has_next = kt + 1 < nk;
+        if constexpr (BIG) {
+            const int far = (nxt + 1 == NBUF) ? 0 : nxt + 1;
+            if (kt + 2 < nk) GPX_DMA_STAGE(far, kt + 2)
+        } else {
+            if (has_next) GPX_DMA_STAGE(nxt, kt + 1)
+        }
+        GPX_LOAD_FRAGS(1, cur_off, 1)
+        GPX_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        GPX_LOAD_FRAGS(0, cur_off, 2)
+        GPX_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        GPX_LOAD_FRAGS(1, cur_off, 3)
+        GPX_MMA(0)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (BIG) {
+            // stage kt+1 must have landed; the DMA of stage kt+2 (the NDMA youngest operations) may stay in flight
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            __syncthreads();
+        }
+        if (has_next) { GPX_LOAD_FRAGS(0, nxt_off, 0) }
+        GPX_MMA(1)
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
     }
-#undef GPX_STAGE
-#undef GPX_GLOAD
-#undef GPX_LSTORE
 #undef GPX_LOAD_FRAGS
 #undef GPX_MMA
-#ifdef GPX_GEMM_STAMP
-    if (lane == 0)   // stamp sums leave through a buffer of their own that no kernel reads
-        for (int q = 0; q < 5; ++q) atomicAdd(&gpx_stamp_sink[q], st_acc[q]);
-#endif
+#undef GPX_DMA_STAGE
 
     if constexpr (BIG) {
 #pragma unroll
