@@ -387,7 +387,8 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
         (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
     h->small_elems = 4096 + h->npad;
-    if (hipMalloc((void **)&h->info_dev, sizeof(int)) != hipSuccess) { gpx_set_error("hipMalloc info failed"); return fail(GPX_ERR_HIP); }
+    if (hipMalloc((void **)&h->info_dev, sizeof(int) * (2 + 2 * h->nblk)) != hipSuccess) { gpx_set_error("hipMalloc info failed"); return fail(GPX_ERR_HIP); }
+    if (hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), h->stream) != hipSuccess) { gpx_set_error("hipMemset info failed"); return fail(GPX_ERR_HIP); }
 
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
     FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
@@ -409,9 +410,20 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
             return fail(info);
         }
     }
-    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
-    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
-    FIT_HIP(hipStreamSynchronize(s));
+    static const bool use_wavefront = getenv("GPX_TRSV_WAVEFRONT") && getenv("GPX_TRSV_WAVEFRONT")[0] == '1';
+    // The single-launch wavefront solves (trsv.hip) are correct but measured slower than the per-step kernels on
+    // MI355X (hand-off + reduction latency on the 128-step critical path: 10 ms vs 5.8 ms at N=16384): opt-in only.
+    if (use_wavefront && h->nblk <= 2048) {   // every workgroup must be resident: 256 CUs x 8 small workgroups
+        int solve_err = 0;
+        if ((rc = trsv_wavefront_pair(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->alpha, h->info_dev + 2, 1, h->info_dev + 1, s, &h->prof))) return fail(rc);
+        FIT_HIP(hipMemcpyAsync(&solve_err, h->info_dev + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+        FIT_HIP(hipStreamSynchronize(s));
+        if (solve_err) { gpx_set_error("wavefront triangular solve timed out waiting for a producer workgroup"); return fail(GPX_ERR_HIP); }
+    } else {
+        if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
+        if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
+        FIT_HIP(hipStreamSynchronize(s));
+    }
 #undef FIT_HIP
     *out = h;
     return 0;

@@ -81,7 +81,7 @@ struct gpx_handle {
     double *y = nullptr;        // [npad] L^-1 t
     double *alpha = nullptr;    // [npad] K^-1 t
     double *Kinv = nullptr;     // [npad, npad] lazily materialised
-    int *info_dev = nullptr;
+    int *info_dev = nullptr;    // [0] potrf info, [1] wavefront-solve error word, [2 .. 2+2*nblk) hand-off flags
     double logdet = 0;
     bool have_logdet = false;
 
@@ -122,6 +122,8 @@ int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, 
                  double *scratch, hipStream_t s, Profiler *prof);
 int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,
                   double *scratch, hipStream_t s, Profiler *prof);
+int trsv_wavefront_pair(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
+                        double *a, int *flags, int epoch, int *err_dev, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
 int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
                           double *mean, double *var, hipStream_t s, Profiler *prof);
