@@ -140,6 +140,17 @@ int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, 
  * info_dev: device int, set to 1-based failing column + col_offset on a non-positive pivot */
 int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset, void *stream);
 
+/* factor block columns [B0,B1) (units of GPX_TILE) of the row-major matrix L (ld, nblk block rows), all updates
+ * from columns < B0 already applied: diagonal square 128 columns at a time + one recursive TRSM for the rows
+ * below.  This is the per-panel step the multi-GPU host (skgpuppy_amd/distributed.py) runs on the panel owner. */
+int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *dinv, double *diag,
+                       int *info_dev, void *stream);
+/* build a handle around an EXISTING factor in HBM (L [npad,npad] with ld == npad, dinv [npad/128,128,128],
+ * diag [npad]; the caller keeps ownership and must keep them alive): solves for alpha; predict / propagate as usual.
+ * Used by the sharded fit, where every rank ends up with the full factor after the panel broadcasts. */
+int gpx_adopt_factor(const double *x, const double *t_centered, int64_t n, int d, const double *theta, double *L_dev,
+                     double *dinv_dev, double *diag_dev, double jitter, void *stream, gpx_handle **out);
+
 #ifdef __cplusplus
 }
 #endif

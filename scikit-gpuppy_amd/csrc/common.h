@@ -67,6 +67,7 @@ struct gpx_handle {
     double w[GPX_MAX_D];
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool external_factor = false;   // L / Dinv / diagL belong to the caller (gpx_adopt_factor)
     hipStream_t s_pan = nullptr;   // side stream for the latency-bound diagonal chain (CU-masked: a few reserved CUs)
     hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
 

@@ -1,0 +1,386 @@
+"""Multi-GPU fit: column panels of K sharded block-cyclically over the ranks of one node.
+
+One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).  The reference has no distributed
+code at all; the structure below is the multi-GPU form of libgpx's own two-level
+right-looking Cholesky (csrc/chol.hip):
+
+  * the N x N matrix is cut into outer panels of PANEL_BLOCKS x 128 columns; rank r owns panels p = r (mod R);
+  * K-build: every rank assembles only the Gram columns of its own panels (no communication);
+  * factorisation, per panel p: the owner factors it (gpx_dev_chol_panel: diagonal chain + one recursive TRSM),
+    the panel (rows below its diagonal, 1024 wide) + its inverted diagonal blocks are BROADCAST (the path's one
+    real exchange step), every rank applies the rank-1024 update to the panels it owns.  Look-ahead: the owner of
+    panel p+1 updates and factors it first and its broadcast is posted asynchronously, so the transfer overlaps
+    with the remaining updates of step p;
+  * every rank unpacks each received panel into its own copy of L, so after the last step all ranks hold the
+    complete factor (34 GB at N = 65536: fits one 288 GB MI355X) and `estimate_many` shards the QUERIES with no
+    further communication; alpha is solved redundantly per rank (4 N^2 bytes of HBM traffic, no exchange).
+
+The schedule (`panel_cholesky`) is written against a small `ops` interface so that it runs unchanged on CPU
+tensors with the gloo backend (tests/test_distributed_gloo.py supplies a torch-CPU `ops`); `GpxOps` is the
+product implementation on libgpx device kernels.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy as np
+
+TILE = 128
+PANEL_BLOCKS = 8     # outer panel = 8 x 128 = 1024 columns (same as csrc/chol.hip CHOL_NBP)
+
+
+class PanelLayout(object):
+    """Block-cyclic ownership of outer column panels."""
+
+    def __init__(self, n, world, panel_blocks=PANEL_BLOCKS):
+        self.n = int(n)
+        self.npad = (self.n + TILE - 1) // TILE * TILE
+        self.nblk = self.npad // TILE
+        self.world = int(world)
+        self.pb = int(panel_blocks)
+        self.npanels = (self.nblk + self.pb - 1) // self.pb
+
+    def blocks(self, p):
+        b0 = p * self.pb
+        return b0, min(b0 + self.pb, self.nblk)
+
+    def owner(self, p):
+        return p % self.world
+
+    def owned(self, rank):
+        return [p for p in range(self.npanels) if self.owner(p) == rank]
+
+
+def panel_cholesky(ops, layout, rank, comm):
+    """Right-looking panel Cholesky with look-ahead; returns when this rank's `ops` holds the complete factor.
+
+    ops : build_panel(p), factor_panel(p), update_panel(q, p), pack_panel(p) -> list of contiguous tensors,
+          recv_buffers(p) -> list of tensors of the same shapes, unpack_panel(p, bufs)
+    comm: broadcast(tensors, src) -> object with .wait()   (asynchronous)
+    """
+    P = layout.npanels
+    mine = layout.owned(rank)
+    for p in mine:
+        ops.build_panel(p)
+
+    def post(p):
+        """owner: factor + pack; everyone: post the (asynchronous) broadcast of panel p."""
+        src = layout.owner(p)
+        if src == rank:
+            ops.factor_panel(p)
+            bufs = ops.pack_panel(p)
+        else:
+            bufs = ops.recv_buffers(p)
+        return bufs, comm.broadcast(bufs, src)
+
+    inflight = post(0)
+    for p in range(P):
+        bufs, work = inflight
+        work.wait()
+        if layout.owner(p) != rank:
+            ops.unpack_panel(p, bufs)
+        nxt = p + 1
+        if nxt < P:
+            if layout.owner(nxt) == rank:
+                ops.update_panel(nxt, p)          # the next panel first ...
+            inflight = post(nxt)                  # ... so its factorisation + broadcast overlap with the rest
+        for q in mine:
+            if q > nxt:
+                ops.update_panel(q, p)
+    ops.finish()
+
+
+# ---------------------------------------------------------------------------------------------------
+# torch.distributed plumbing
+# ---------------------------------------------------------------------------------------------------
+class _Work(object):
+    def __init__(self, works):
+        self.works = works
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
+class TorchComm(object):
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+
+    def broadcast(self, tensors, src):
+        return _Work([self.dist.broadcast(t, src=src, group=self.group, async_op=True) for t in tensors])
+
+
+class HostStagedComm(object):
+    """Rehearsal transport: device tensors are broadcast through host memory over a CPU backend (gloo).  Lets the
+    N > 1 code path run with several ranks sharing ONE GPU (RCCL refuses duplicate devices); never used by bench.py
+    on a real multi-GPU node."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+
+    def broadcast(self, tensors, src):
+        comm = self
+
+        class _W(object):
+            def wait(self_w):
+                for t in tensors:
+                    h = t.detach().cpu().contiguous()
+                    comm.dist.broadcast(h, src=src, group=comm.group)
+                    if comm.dist.get_rank(comm.group) != src:
+                        t.copy_(h)
+        return _W()
+
+
+# ---------------------------------------------------------------------------------------------------
+# product ops: libgpx kernels on this rank's GPU
+# ---------------------------------------------------------------------------------------------------
+class GpxOps(object):
+    def __init__(self, x_dev, theta, layout, device):
+        import torch
+        from . import _gpx
+        self.torch, self._gpx, self.lib = torch, _gpx, _gpx.lib
+        self.layout = layout
+        self.x = x_dev                                  # [n, d] float64 on `device`
+        self.n, self.d = x_dev.shape
+        self.theta = np.ascontiguousarray(theta, dtype=np.float64)
+        with np.errstate(divide="ignore"):
+            self.vt = float(np.exp(self.theta[1]))
+        npad, nblk = layout.npad, layout.nblk
+        self.L = torch.empty((npad, npad), dtype=torch.float64, device=device)
+        self.Dinv = torch.empty((nblk, TILE, TILE), dtype=torch.float64, device=device)
+        self.diag = torch.empty(npad, dtype=torch.float64, device=device)
+        self.info = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    @staticmethod
+    def _p(t, byte_offset=0):
+        return ctypes.c_void_p(t.data_ptr() + byte_offset)
+
+    def _Lptr(self, row, col):
+        return ctypes.c_void_p(self.L.data_ptr() + 8 * (row * self.layout.npad + col))
+
+    def build_panel(self, p):
+        """Gram columns of panel p, rows from its diagonal down (+vt on the diagonal, identity padding)."""
+        b0, b1 = self.layout.blocks(p)
+        c0, c1 = b0 * TILE, b1 * TILE
+        n, d, npad = self.n, self.d, self.layout.npad
+        if c0 >= n:      # panel entirely in the padding: identity
+            self.L[c0:, c0:c1].zero_()
+            self.L[c0:c1, c0:c1].fill_diagonal_(1.0)
+            return
+        xi = ctypes.c_void_p(self.x.data_ptr() + 8 * c0 * d)
+        st = self.lib.gpx_dev_gram(xi, n - c0, xi, min(c1, n) - c0, d, self._gpx.ptr(self.theta), self.vt, 0, 1,
+                                   self._Lptr(c0, c0), npad, npad - c0, c1 - c0, self._stream())
+        self._gpx.check(st, "gpx_dev_gram(panel %d)" % p)
+
+    def factor_panel(self, p):
+        b0, b1 = self.layout.blocks(p)
+        st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
+                                         self._p(self.diag), self._p(self.info), self._stream())
+        self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
+
+    def update_panel(self, q, p):
+        """C[rows >= q0, panel q] -= L[rows >= q0, panel p] L[panel-q rows, panel p]^T"""
+        pb0, pb1 = self.layout.blocks(p)
+        qb0, qb1 = self.layout.blocks(q)
+        npad = self.layout.npad
+        r0 = qb0 * TILE
+        A = self._Lptr(r0, pb0 * TILE)
+        C = self._Lptr(r0, r0)
+        st = self.lib.gpx_dev_gemm_nt(A, npad, A, npad, C, npad, npad - r0, (qb1 - qb0) * TILE, (pb1 - pb0) * TILE,
+                                      -1.0, 1.0, 0, self._stream())
+        self._gpx.check(st, "panel update (%d <- %d)" % (q, p))
+
+    def _panel_views(self, p):
+        b0, b1 = self.layout.blocks(p)
+        return self.L[b0 * TILE:, b0 * TILE:b1 * TILE], self.Dinv[b0:b1], self.diag[b0 * TILE:b1 * TILE]
+
+    def pack_panel(self, p):
+        panel, dinv, diag = self._panel_views(p)
+        return [panel.contiguous(), dinv, diag]        # dinv / diag slices are already contiguous
+
+    def recv_buffers(self, p):
+        panel, dinv, diag = self._panel_views(p)
+        return [self.torch.empty(panel.shape, dtype=panel.dtype, device=panel.device), dinv, diag]
+
+    def unpack_panel(self, p, bufs):
+        panel, _dinv, _diag = self._panel_views(p)
+        panel.copy_(bufs[0])
+
+    def finish(self):
+        self.torch.cuda.current_stream().synchronize()
+        info = int(self.info.item())
+        if info > 0:
+            raise np.linalg.LinAlgError("covariance matrix not positive definite (leading minor %d)" % info)
+
+
+class ShardedGaussianProcess(object):
+    """GaussianProcess over R GPUs: sharded K-build + panel-broadcast Cholesky, query-sharded estimate_many.
+    Must be constructed collectively by every rank of `group` with identical (x, t, theta)."""
+
+    def __init__(self, x, t, theta_min, group=None, device=None, comm=None):
+        import torch
+        import torch.distributed as dist
+        from . import _gpx
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.x = x
+        self.n, self.d = np.shape(x)
+        self.meant = np.mean(t)
+        self.t = np.asarray(t, dtype=np.float64) - self.meant
+        self.theta_min = np.ascontiguousarray(theta_min, dtype=np.float64)
+        self._x_dev = torch.as_tensor(_gpx.f64(x)).to(self.device)
+        self._t_dev = torch.as_tensor(_gpx.f64(self.t)).to(self.device)
+        self.layout = PanelLayout(self.n, self.world)
+        self._comm = comm if comm is not None else TorchComm(group)
+        self._ops = None
+        self._h = ctypes.c_void_p()
+        self.refit()
+
+    def refit(self):
+        """(re)run the sharded fit on the resident inputs -- one benchmark `fit` step."""
+        from . import _gpx
+        self.close()
+        ops = GpxOps(self._x_dev, self.theta_min, self.layout, self.device)
+        panel_cholesky(ops, self.layout, self.rank, self._comm)
+        self._ops = ops
+        st = _gpx.lib.gpx_adopt_factor(ctypes.c_void_p(self._x_dev.data_ptr()), ctypes.c_void_p(self._t_dev.data_ptr()),
+                                       self.n, self.d, _gpx.ptr(self.theta_min), ops._p(ops.L), ops._p(ops.Dinv),
+                                       ops._p(ops.diag), 0.0, None, ctypes.byref(self._h))
+        _gpx.check(st, "gpx_adopt_factor")
+
+    def close(self):
+        from . import _gpx
+        if getattr(self, "_h", None):
+            _gpx.lib.gpx_free(self._h)
+            self._h = ctypes.c_void_p()
+        self._ops = None
+
+    __del__ = close
+
+    def shard(self, m):
+        """[lo, hi) of the m queries this rank serves."""
+        per = (m + self.world - 1) // self.world
+        lo = min(m, self.rank * per)
+        return lo, min(m, lo + per)
+
+    def estimate_local(self, xs_dev, mean_dev, var_dev):
+        """predict this rank's resident query shard (device tensors, mean WITHOUT meant)."""
+        from . import _gpx
+        m = xs_dev.shape[0]
+        st = _gpx.lib.gpx_predict(self._h, ctypes.c_void_p(xs_dev.data_ptr()), m, ctypes.c_void_p(mean_dev.data_ptr()),
+                                  ctypes.c_void_p(var_dev.data_ptr()))
+        _gpx.check(st, "gpx_predict")
+
+    def estimate_many(self, x_stars):
+        """Same contract as GaussianProcess.estimate_many (skgpuppy/GaussianProcess.py:68-80); every rank returns
+        the full arrays (query shards are all-gathered)."""
+        import torch
+        import torch.distributed as dist
+        from . import _gpx
+        xs = _gpx.f64(np.array(x_stars))
+        m = xs.shape[0]
+        lo, hi = self.shard(m)
+        per = (m + self.world - 1) // self.world
+        out = torch.zeros((2, per), dtype=torch.float64, device=self.device)
+        if hi > lo:
+            xs_dev = torch.as_tensor(xs[lo:hi]).to(self.device)
+            self.estimate_local(xs_dev, out[0, :hi - lo], out[1, :hi - lo])
+        host = out.cpu()                                  # small (2 x m/R doubles): gathered on the host backend-agnostically
+        gathered = [torch.empty_like(host) for _ in range(self.world)]
+        dist.all_gather(gathered, host, group=self.group)
+        full = torch.cat(gathered, dim=1).numpy()[:, :m]
+        return full[0] + self.meant, full[1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py --gpus N (N > 1): strong scaling of fit + estimate_many at config C4
+# ---------------------------------------------------------------------------------------------------
+def bench_main(args):
+    import torch
+    import torch.distributed as dist
+    from . import _gpx
+    import bench as bench_mod
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    torch.cuda.set_device(local)
+    _gpx.check(_gpx.lib.gpx_set_device(local), "gpx_set_device")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    wl = bench_mod.WORKLOADS[args.workload or "c4"]
+    N, d, M = wl["N"], wl["d"], wl["M"]
+    x, t, xs, theta = bench_mod.recipe(N, d, M)
+    dev = torch.device("cuda", local)
+    gp = ShardedGaussianProcess(x, t, theta, device=dev)          # first fit = warm-up of allocations / RCCL rings
+    lo, hi = gp.shard(M)
+    xs_dev = torch.as_tensor(xs[lo:hi]).to(dev)
+    mean_d = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+    var_d = torch.empty(hi - lo, dtype=torch.float64, device=dev)
+    t_fit = t_pred = 0.0
+
+    def step(timed):
+        nonlocal t_fit, t_pred
+        a = time.perf_counter()
+        gp.refit()
+        torch.cuda.synchronize()
+        b = time.perf_counter()
+        gp.estimate_local(xs_dev, mean_d, var_d)
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        if timed:
+            t_fit += b - a
+            t_pred += c - b
+
+    for _ in range(args.warmup):
+        step(False)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0, t_fit, t_pred], dtype=torch.float64, device=dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    el, tf, tp = [float(v) for v in elapsed.cpu()]
+    if rank == 0:
+        flops = N ** 3 / 3.0 + float(N) * N * M
+        print(json.dumps({
+            "metric": "GP fit+predict pts/sec (K+Cholesky, N=%d d=%d)" % (N, d),
+            "value": (N + M) * args.steps / el,
+            "unit": "pts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "%s: N=%d d=%d M=%d, column panels of K (1024 wide) block-cyclic over %d GPUs, "
+                                   "RCCL panel broadcast, query-sharded estimate_many" % ((args.workload or "c4").upper(), N, d, M, world),
+                       "global_batch": N + M, "parallelism": "panel-sharded x%d" % world},
+            "fit_ms": tf / args.steps * 1e3,
+            "predict_ms": tp / args.steps * 1e3,
+            "roofline": {"kernel": "gemm_nt_f64_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                         "achieved": flops * args.steps / el / 1e12 / world, "peak": bench_mod.FP64_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops * args.steps / el / 1e12 / world / bench_mod.FP64_MFMA_PEAK_TFLOPS,
+                         "traffic": None,
+                         "note": "whole-step algorithmic flops (N^3/3 + N^2 M) per GPU-second; per-kernel event timing is the N=1 line"},
+        }))
+    gp.close()
+    dist.destroy_process_group()

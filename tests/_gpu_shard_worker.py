@@ -1,0 +1,49 @@
+"""Worker for the GPU test of the sharded fit: R ranks share cuda:0 (rehearsal transport over gloo/host staging)
+and must reproduce the single-GPU GaussianProcess and the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "scikit-gpuppy_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import skgpuppy_amd as sk  # noqa: E402
+from skgpuppy_amd.distributed import HostStagedComm, ShardedGaussianProcess  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    N, d, M = int(sys.argv[1]), int(sys.argv[2]), 333
+    rng = np.random.RandomState(20240 + N + d)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    torch.cuda.set_device(0)
+    gp = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=HostStagedComm())
+    mean, var = gp.estimate_many(xs)
+    ok = True
+    if rank == 0:
+        ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+        m1, v1 = ref.estimate_many(xs)
+        og = orc.OracleGP(x, t, theta)
+        om, ov = og.estimate_many(xs)
+        e1 = max(np.abs(mean - m1).max(), np.abs(var - v1).max())
+        e2 = max(np.abs(mean - om).max(), np.abs(var - ov).max())
+        print("sharded vs single-GPU: %.3e   sharded vs oracle: %.3e" % (e1, e2))
+        ok = e1 < 1e-10 and np.allclose(mean, om, rtol=1e-6, atol=1e-9) and np.allclose(var, ov, rtol=1e-6, atol=2e-9)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    gp.close()
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1.0 else 1)
+
+
+if __name__ == "__main__":
+    main()

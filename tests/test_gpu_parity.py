@@ -382,3 +382,20 @@ def test_full_size_properties(N, d):
     mu, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(np.full(d, 5.0), S)
     me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(np.full(d, 5.0), S)
     assert mu == pytest.approx(me, abs=1e-2) and va == pytest.approx(ve, abs=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 code path on the one GPU of the test box: 2 ranks share cuda:0, panels travel over gloo (host staged)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,d", [(2500, 4)])
+def test_sharded_fit_two_ranks_share_one_gpu(N, d):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29733", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(N), str(d)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "sharded vs single-GPU" in r.stdout
