@@ -66,6 +66,45 @@ def cpu_baseline(d, budget_n=5120):
     return N, M, t1 - t0, t2 - t1
 
 
+def propagate_section(lib, _gpx, vp, xd, td, th, N, d):
+    """Outside the timed region: one propagate_GA (Approx and Exact) on a fitted handle (config C3 of BASELINE.json:
+    u = 5*1_d, Sigma = 0.01 I), with the HBM-bound kernels timed by HIP events on the handle's stream."""
+    h = ctypes.c_void_p()
+    _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "gpx_fit")
+    lib.gpx_profile_enable(h, 1)
+    lib.gpx_profile_reset(h)
+    u = np.full(d, 5.0)
+    S = 0.01 * np.eye(d)
+    o = [ctypes.c_double() for _ in range(4)]
+    res = {}
+    t0 = time.perf_counter()
+    kinv_probe = ctypes.c_double()
+    # first propagate call materialises Kinv = L^-T L^-1 on the device (lazy, once per fit)
+    _gpx.check(lib.gpx_propagate_approx(h, _gpx.ptr(u), _gpx.ptr(S), *[ctypes.byref(x) for x in o]), "approx")
+    t1 = time.perf_counter()
+    _gpx.check(lib.gpx_propagate_approx(h, _gpx.ptr(u + 0.25), _gpx.ptr(S), *[ctypes.byref(x) for x in o]), "approx")
+    t2 = time.perf_counter()
+    _gpx.check(lib.gpx_propagate_approx(h, _gpx.ptr(u + 0.25), _gpx.ptr(2 * S), *[ctypes.byref(x) for x in o]), "approx")
+    t3 = time.perf_counter()
+    m, v = ctypes.c_double(), ctypes.c_double()
+    _gpx.check(lib.gpx_propagate_exact(h, _gpx.ptr(u), _gpx.ptr(S), ctypes.byref(m), ctypes.byref(v)), "exact")
+    t4 = time.perf_counter()
+    res["first_call_incl_Kinv_build_ms"] = (t1 - t0) * 1e3
+    res["approx_new_u_ms"] = (t2 - t1) * 1e3
+    res["approx_same_u_new_Sigma_ms"] = (t3 - t2) * 1e3
+    res["exact_ms"] = (t4 - t3) * 1e3
+    for cls, name in ((_gpx.K_QUAD, "approx_kinv_pass"), (_gpx.K_EXACT, "exact_sum")):
+        n_, ms_, w_ = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+        lib.gpx_profile_read(h, cls, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(w_))
+        if n_.value:
+            per = ms_.value / n_.value
+            nbytes = 8.0 * N * N if cls == _gpx.K_QUAD else 4.0 * N * N      # exact_sum visits the j <= i half only
+            res[name] = {"launches": n_.value, "avg_ms": per, "kinv_bytes": nbytes,
+                         "hbm_GBs": nbytes / (per * 1e-3) / 1e9, "frac_of_8TBs": nbytes / (per * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    lib.gpx_free(h)
+    return res
+
+
 def run_single(args):
     import skgpuppy_amd  # noqa: F401
     from skgpuppy_amd import _gpx
@@ -160,6 +199,8 @@ def run_single(args):
             _gpx.KERNEL_CLASS_NAMES[k]: {"launches": prof[k][0] / args.steps, "ms": prof[k][1] / args.steps,
                                          "work": prof[k][2] / args.steps} for k in range(7) if prof[k][0]},
     }
+    if not args.no_propagate:
+        out["propagate"] = propagate_section(lib, _gpx, vp, xd, td, th, N, d)
     if not args.no_cpu:
         Ns, Ms, tf, tp = cpu_baseline(d)
         v_s = (Ns + Ms) / (tf + tp)
@@ -184,6 +225,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-propagate", action="store_true", help="skip the (untimed) propagate_GA section")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1:

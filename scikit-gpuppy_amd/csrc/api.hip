@@ -15,6 +15,8 @@
 #include "common.h"
 
 // launchers living in propagate.hip
+int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const double *V, double *KV, hipStream_t s,
+                     Profiler *prof);
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
 int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
                      const double *bT, const double *e, const double *F, double *partial, double *out_dev, hipStream_t s,
@@ -707,10 +709,7 @@ static int prepare_u(gpx_handle *h, const double *u)
     GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
     GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
     // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6
-    {
-        ProfScope ps(&h->prof, s, GPX_K_QUAD, 8.0 * (double)h->npad * (double)h->npad);
-        GPX_TRY(launch_gemm_nt(h->V, h->npad, h->Kinv, h->npad, h->KV, h->npad, TILE, h->npad, h->npad, 1.0, 0.0, 0, s, nullptr));
-    }
+    GPX_TRY(launch_kinv_pass(h->Kinv, h->npad, h->npad, h->d + 1, h->V, h->KV, s, &h->prof));
     memcpy(h->u, uh, sizeof(double) * h->d);
     h->have_u = true;
     return 0;

@@ -106,6 +106,67 @@ int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// KV[c][i] = sum_j Kinv[i][j] V[c][j] for c < nc: the ONE pass over Kinv that feeds every quadratic form of
+// the Approx propagation (loops K2..K6 of the reference, UncertaintyPropagation2.pyx:221-257,340-380, each of
+// which re-reads the whole N x N matrix serially).  HBM-bound: 8 N^2 bytes.
+// Workgroup = R rows x all columns; thread = column j (512-byte coalesced Kinv reads per wave and row); the thread's
+// nc values V[.][j] sit in registers and are reused for the R rows; per-thread partial sums acc[R][NC] are
+// reduced across the wave with shuffles and across the 4 waves through LDS (fixed order: deterministic).
+// ---------------------------------------------------------------------------------------------
+template <int NC, int R>
+__global__ __launch_bounds__(256) void kinv_pass_kernel(const double *__restrict__ Kinv, long ld, long npad, int nc,
+                                                       const double *__restrict__ V, double *__restrict__ KV)
+{
+    __shared__ double red[4][R * NC];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const long i0 = (long)blockIdx.x * R;
+    double acc[R][NC];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
+    for (long j = t; j < npad; j += 256) {
+        double v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = (c < nc) ? V[(long)c * npad + j] : 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const double k = Kinv[(i0 + r) * ld + j];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] = fma(k, v[c], acc[r][c]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double s = wave_sum_p(acc[r][c]);
+            if (lane == 0) red[wave][r * NC + c] = s;
+        }
+    __syncthreads();
+    for (int e = t; e < R * NC; e += 256) {
+        const int r = e / NC, c = e - r * NC;
+        if (c < nc) KV[(long)c * npad + i0 + r] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    }
+}
+
+int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const double *V, double *KV, hipStream_t s,
+                     Profiler *prof)
+{
+    ProfScope ps(prof, s, GPX_K_QUAD, 8.0 * (double)npad * (double)npad);
+    if (nc <= 9)
+        hipLaunchKernelGGL((kinv_pass_kernel<9, 8>), dim3((unsigned)(npad / 8)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+    else if (nc <= 17)
+        hipLaunchKernelGGL((kinv_pass_kernel<17, 4>), dim3((unsigned)(npad / 4)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+    else if (nc <= 33)
+        hipLaunchKernelGGL((kinv_pass_kernel<33, 2>), dim3((unsigned)(npad / 2)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+    else
+        hipLaunchKernelGGL((kinv_pass_kernel<65, 1>), dim3((unsigned)npad), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 // full C / J / H arrays for the host-side attributes C_ux, J_ux, H_ux
 __global__ __launch_bounds__(256) void cjh_kernel(const double *__restrict__ x, long n, int d,
                                                  const double *__restrict__ u, const double *__restrict__ w, double v,
@@ -180,49 +241,87 @@ __global__ __launch_bounds__(256) void exact_build_kernel(const double *__restri
     lm[i] = Ci * nc1 * exp(0.5 * qd);
 }
 
+// exp(x) for the pair kernel: x = e_i + e_j + b_i.a_j is <= ~0 by construction (it is the log of L_ij / (F_i F_j nc2),
+// a product of Gaussian factors), so only the plain Cody-Waite path is needed: n = rint(x log2 e), r = x - n ln2
+// (two-term), degree-12 Taylor polynomial on |r| <= ln2/2 (truncation 1.7e-16), scaled by v_ldexp_f64 (which also
+// produces the denormal / zero results for very negative x).  ~18 fp64 ops instead of the ~45 of the generic exp.
+__device__ __forceinline__ double exp_nonpos(double x)
+{
+    x = fmax(x, -750.0);
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;          // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);      // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);      // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);      // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);      // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);      // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);      // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);      // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);      // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);      // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // S = sum_ij (Kinv_ij - beta_i beta_j) F_i F_j exp(e_i + e_j + b_i . a_j); the caller multiplies by nc2.
-// Workgroup = 16 rows x all columns; thread = column j (stride 256).  partial[blockIdx.x] = block sum.
+// Kinv and L_ij are symmetric: only the pairs j <= i are visited (weight 2 off the diagonal), halving both the
+// HBM bytes (4 N^2) and the exp count of the reference's full double loop (UncertaintyPropagation2.pyx:173-179).
+// Workgroup = EXR rows; thread = column j (stride 256, coalesced Kinv reads); heavy (bottom) row blocks first.
+constexpr int EXR = 8;   // rows per workgroup: 8 keeps the kernel at <=128 VGPRs (2+ waves/SIMD hide the HBM latency)
 template <int DMAX>
-__global__ __launch_bounds__(256) void exact_sum_kernel(const double *__restrict__ Kinv, long ld, long npad, int d,
+__global__ __launch_bounds__(256, 2) void exact_sum_kernel(const double *__restrict__ Kinv, long ld, long npad, int d,
                                                        const double *__restrict__ beta, const double *__restrict__ aT,
                                                        const double *__restrict__ bT, const double *__restrict__ e,
                                                        const double *__restrict__ F, double *__restrict__ partial)
 {
-    __shared__ double bs[16][DMAX];      // b_i for the block's 16 rows (broadcast reads)
-    __shared__ double rs[16][3];         // e_i, F_i, beta_i
+    __shared__ __attribute__((aligned(16))) double bs[EXR][DMAX];   // b_i for the block's 16 rows (broadcast reads), zero padded
+    __shared__ double rs[EXR][3];                                   // e_i, F_i, beta_i
     __shared__ double ws[4];
     const int t = threadIdx.x;
-    const long i0 = (long)blockIdx.x * 16;
-    for (int q = t; q < 16 * d; q += 256) { const int r = q / d, k = q - r * d; bs[r][k] = bT[(long)k * npad + i0 + r]; }
-    if (t < 16) { rs[t][0] = e[i0 + t]; rs[t][1] = F[i0 + t]; rs[t][2] = beta[i0 + t]; }
+    const int rb = gridDim.x - 1 - blockIdx.x;
+    const long i0 = (long)rb * EXR;
+    for (int q = t; q < EXR * DMAX; q += 256) {
+        const int r = q / DMAX, k = q - r * DMAX;
+        bs[r][k] = (k < d) ? bT[(long)k * npad + i0 + r] : 0.0;
+    }
+    if (t < EXR) { rs[t][0] = e[i0 + t]; rs[t][1] = F[i0 + t]; rs[t][2] = beta[i0 + t]; }
     __syncthreads();
 
-    double acc[16];
+    double acc[EXR];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0;
+    for (int r = 0; r < EXR; ++r) acc[r] = 0.0;
 
-    for (long j = t; j < npad; j += 256) {
+    for (long j = t; j < i0 + EXR; j += 256) {
         double aj[DMAX];
 #pragma unroll
         for (int k = 0; k < DMAX; ++k) aj[k] = (k < d) ? aT[(long)k * npad + j] : 0.0;
         const double ej = e[j], Fj = F[j], bj = beta[j];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < EXR; ++r) {
             double dot = rs[r][0] + ej;
 #pragma unroll
-            for (int k = 0; k < DMAX; ++k)
-                if (k < d) dot = fma(bs[r][k], aj[k], dot);
+            for (int k = 0; k < DMAX; k += 2) {
+                const v2d b2 = *reinterpret_cast<const v2d *>(&bs[r][k]);
+                dot = fma(b2.x, aj[k], dot);
+                dot = fma(b2.y, aj[k + 1], dot);
+            }
             const double kij = Kinv[(i0 + r) * ld + j];
-            acc[r] = fma((kij - rs[r][2] * bj) * Fj, exp(dot), acc[r]);
+            const long i = i0 + r;
+            const double wgt = (j < i) ? 2.0 : ((j == i) ? 1.0 : 0.0);
+            acc[r] = fma((kij - rs[r][2] * bj) * (Fj * wgt), exp_nonpos(dot), acc[r]);
         }
     }
     double s = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s = fma(acc[r], rs[r][1], s);
+    for (int r = 0; r < EXR; ++r) s = fma(acc[r], rs[r][1], s);
     s = wave_sum_p(s);
     if ((t & 63) == 0) ws[t >> 6] = s;
     __syncthreads();
-    if (t == 0) partial[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (t == 0) partial[rb] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
 __global__ __launch_bounds__(256) void sum_vector_kernel(const double *__restrict__ p, long n, double *out)
@@ -240,11 +339,13 @@ int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const 
                      const double *bT, const double *e, const double *F, double *partial, double *out_dev,
                      hipStream_t s, Profiler *prof)
 {
-    const unsigned nblk = (unsigned)(npad / 16);
+    const unsigned nblk = (unsigned)(npad / EXR);
     {
         // algorithmic flops: N^2 (2d + ~25) + N^2 exp
-        ProfScope ps(prof, s, GPX_K_EXACT, (double)npad * (double)npad * (2.0 * d + 25.0));
-        if (d <= 4)
+        ProfScope ps(prof, s, GPX_K_EXACT, 0.5 * (double)npad * (double)npad * (2.0 * d + 25.0));   // j <= i pairs only
+        if (d <= 2)
+            hipLaunchKernelGGL(exact_sum_kernel<2>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        else if (d <= 4)
             hipLaunchKernelGGL(exact_sum_kernel<4>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
         else if (d <= 8)
             hipLaunchKernelGGL(exact_sum_kernel<8>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
