@@ -103,6 +103,12 @@ int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out /* [d] */)
 int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var);
 int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean);
 
+/* ---- "next" row f1: hyper-parameter likelihood at the handle's theta
+ * (Covariance._negativeloglikelihood / _d_nll_d_theta, skgpuppy/Covariance.py:197-216, :266-282, :605-657) ----
+ * nll = N/2 log 2pi + 1/2 log det K + 1/2 t^T K^-1 t ;  grad_out[2+d] = d nll / d theta. */
+int gpx_nll(gpx_handle *h, double *nll);
+int gpx_nll_grad(gpx_handle *h, double *grad_out);
+
 /* ---- measurement: per-kernel-class GPU timings taken with HIP events on the handle's stream ----
  * gpx_profile_enable(h,1) brackets every launch of the listed kernel classes with an event pair;
  * gpx_profile_read sums them (it synchronises the stream).  work = algorithmic flops (GEMM, POTRF,

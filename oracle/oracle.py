@@ -137,6 +137,54 @@ def jacobian(u, xi, theta):
     return np.atleast_2d(-d * w * e).T
 
 
+def d_gram_d_theta(x, theta, j):
+    """dK/dtheta_j  (GaussianCovariance._d_cov_matrix_d_theta, Covariance.py:505-512, and
+    _d_cov_matrix_d_theta_ij :605-657): j=0 -> noise-free Gram, j=1 -> vt I, j>=2 -> -1/2 Kf w_k (dx_k)^2."""
+    _v, vt, w = unpack_theta(theta)
+    x = np.asarray(x, dtype=float)
+    n = len(x)
+    if j == 1:
+        return np.eye(n) * vt
+    Kf = gram_ij(x, x, theta)
+    if j == 0:
+        return Kf
+    xk = x[:, j - 2][None, :]
+    dsq = -2.0 * np.dot(xk.T, xk) + np.tile(xk * xk, (n, 1)) + np.tile((xk * xk).T, (1, n))
+    return -0.5 * Kf * dsq * w[j - 2]
+
+
+def nll(x, t, theta):
+    """N/2 log 2pi + 1/2 logdet K + 1/2 t^T Kinv t  (Covariance._negativeloglikelihood, Covariance.py:197-216);
+    t is used as passed (the reference hands the centred targets in, GaussianProcess.py:39)."""
+    t = np.asarray(t, dtype=float)
+    K = gram(x, theta)
+    logdet = np.linalg.slogdet(K)[1]
+    Kinv = inv(K)
+    return len(x) / 2.0 * np.log(2 * np.pi) + 0.5 * logdet + 0.5 * np.dot(t, np.dot(Kinv, t))
+
+
+def nll_grad(x, t, theta):
+    """Covariance._d_nll_d_theta (Covariance.py:266-282): 1/2 tr(Kinv dK_j) - 1/2 t^T Kinv dK_j Kinv t."""
+    t = np.asarray(t, dtype=float)
+    Kinv = inv(gram(x, theta))
+    a = np.dot(Kinv, t)
+    g = []
+    for j in range(len(theta)):
+        dK = d_gram_d_theta(x, theta, j)
+        g.append(0.5 * np.dot(np.ravel(Kinv.T), np.ravel(dK)) - 0.5 * np.dot(a, np.dot(dK, a)))
+    return np.array(g)
+
+
+def theta_start(x, t):
+    """GaussianCovariance.get_theta (Covariance.py:453-459)."""
+    n, d = np.shape(x)
+    th = np.ones(2 + d)
+    th[0] = np.log(np.var(t))
+    th[1] = np.log(np.var(t) / 4)
+    th[2:] = -2 * np.log((np.max(x, 0) - np.min(x, 0)) / 2.0)
+    return th
+
+
 # --------------------------------------------------------------------------------------------
 # L2: GP object  (reference: skgpuppy/GaussianProcess.py)
 # --------------------------------------------------------------------------------------------

@@ -15,6 +15,8 @@
 #include "common.h"
 
 // launchers living in propagate.hip
+int launch_nll_grad(const double *Kinv, int64_t ld, int64_t n, int64_t npad, int d, const double *alpha, const double *xw,
+                    double v, double *partial, double *out_dev, int *dmax_used, hipStream_t s, Profiler *prof);
 int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const double *V, double *KV, hipStream_t s,
                      Profiler *prof);
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
@@ -910,6 +912,53 @@ extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigm
     CHECK_H(h);
     if (!u || !Sigma || !mean) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     return exact_common(h, u, Sigma, false, mean, nullptr);
+}
+
+// ---- "next" row f1: negative log likelihood and its gradient at the handle's theta ----------------------------------
+extern "C" int gpx_nll(gpx_handle *h, double *nll)
+{
+    CHECK_H(h);
+    if (!nll) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    double logdet = 0.0;
+    GPX_TRY(gpx_logdet(h, &logdet));
+    std::vector<std::pair<const double *, const double *>> pr;
+    pr.push_back({h->t, h->alpha});
+    GPX_TRY(launch_dot_pairs(pr, h->npad, h->small, h->stream));
+    double ta = 0.0;
+    GPX_HIP(hipMemcpyAsync(&ta, h->small, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    // N/2 log(2 pi) + 1/2 log det K + 1/2 t^T K^-1 t     (skgpuppy/Covariance.py:197-216)
+    *nll = 0.5 * (double)h->n * log(2.0 * M_PI) + 0.5 * logdet + 0.5 * ta;
+    return 0;
+}
+
+extern "C" int gpx_nll_grad(gpx_handle *h, double *grad_out)
+{
+    CHECK_H(h);
+    if (!grad_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    GPX_TRY(ensure_kinv(h));
+    const int d = h->d;
+    double *buf = nullptr;
+    const int64_t nb = h->npad / 8;
+    GPX_TRY(dalloc(&buf, nb * (GPX_MAX_D + 2) + GPX_MAX_D + 2));
+    double *outd = buf + nb * (GPX_MAX_D + 2);
+    int dm = 0;
+    int rc = launch_nll_grad(h->Kinv, h->npad, h->n, h->npad, d, h->alpha, h->xs_w, h->v, buf, outd, &dm, h->stream, &h->prof);
+    double o[GPX_MAX_D + 2];
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(o, outd, sizeof(double) * (dm + 2), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    } else (void)hipStreamSynchronize(h->stream);
+    dfree(buf);
+    if (rc) return rc;
+    GPX_HIP(e);
+    std::vector<double> g(d + 2);
+    g[0] = 0.5 * o[0];                                   // dK/dtheta_0 = Kf            (Covariance.py:633-639)
+    g[1] = 0.5 * (h->vt + h->jitter * 0.0) * o[dm + 1];  // dK/dtheta_1 = vt I          (Covariance.py:505-510)
+    for (int k = 0; k < d; ++k) g[2 + k] = -0.25 * o[1 + k];   // dK/dtheta_{2+k} = -1/2 Kf w_k dx_k^2 (:643-657); w_k is in the scaled inputs
+    GPX_HIP(hipMemcpy(grad_out, g.data(), sizeof(double) * (d + 2), hipMemcpyDefault));
+    return 0;
 }
 
 // ---- profiling ---------------------------------------------------------------------------------

@@ -324,6 +324,108 @@ __global__ __launch_bounds__(256, 2) void exact_sum_kernel(const double *__restr
     if (t == 0) partial[rb] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Gradient of the negative log likelihood ("next" row f1: Covariance._d_nll_d_theta, skgpuppy/Covariance.py:266-282
+// with GaussianCovariance._d_cov_matrix_d_theta_ij, :605-657).  The reference forms 2+d derivative matrices dK/dtheta_j
+// (N x N each) and evaluates 1/2 tr(Kinv dK) - 1/2 a^T dK a per parameter; here ONE pass over the j <= i half of Kinv
+// recomputes the noise-free Gram entry Kf_ij on the fly and accumulates, with M_ij = Kinv_ij - a_i a_j,
+//   S_0 = sum M_ij Kf_ij,   S_{1+k} = sum M_ij Kf_ij (x_ik - x_jk)^2,   T = tr(Kinv) - a^T a
+// so that  dNLL/dtheta_0 = S_0/2,  dNLL/dtheta_1 = vt T/2,  dNLL/dtheta_{2+k} = -w_k S_{1+k}/4.
+// partial[block][DMAX+2]: [0] = S_0, [1..d] = S_k, [DMAX+1] = T.
+// ---------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ __launch_bounds__(256, 2) void nll_grad_kernel(const double *__restrict__ Kinv, long ld, long n, long npad, int d,
+                                                         const double *__restrict__ alpha, const double *__restrict__ xw,
+                                                         double v, double *__restrict__ partial)
+{
+    constexpr int R = 8;
+    __shared__ double xs[R][DMAX];     // sqrt(w)-scaled rows of the block (broadcast reads)
+    __shared__ double as[R];
+    __shared__ double red[4][DMAX + 2];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int rb = gridDim.x - 1 - blockIdx.x;
+    const long i0 = (long)rb * R;
+    for (int q = t; q < R * DMAX; q += 256) {
+        const int r = q / DMAX, k = q - r * DMAX;
+        xs[r][k] = (k < d && i0 + r < n) ? xw[(i0 + r) * d + k] : 0.0;
+    }
+    if (t < R) as[t] = alpha[i0 + t];
+    __syncthreads();
+    double acc[DMAX + 2];
+#pragma unroll
+    for (int c = 0; c < DMAX + 2; ++c) acc[c] = 0.0;
+    for (long j = t; j < i0 + R && j < n; j += 256) {
+        double xj[DMAX];
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) xj[k] = (k < d) ? xw[j * d + k] : 0.0;
+        const double aj = alpha[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long i = i0 + r;
+            if (i >= n || j > i) continue;
+            double q = 0.0, dk[DMAX];
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                const double df = xs[r][k] - xj[k];
+                dk[k] = df * df;               // = w_k (x_ik - x_jk)^2  (inputs are sqrt(w)-scaled)
+                q += dk[k];
+            }
+            const double kij = Kinv[i * ld + j];
+            const double wgt = (j < i) ? 2.0 : 1.0;
+            const double m = (kij - as[r] * aj) * wgt * v * exp_nonpos(-0.5 * q);
+            acc[0] += m;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) acc[1 + k] = fma(m, dk[k], acc[1 + k]);
+            if (j == i) acc[DMAX + 1] += kij - as[r] * aj;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < DMAX + 2; ++c) {
+        const double s = wave_sum_p(acc[c]);
+        if (lane == 0) red[wave][c] = s;
+    }
+    __syncthreads();
+    if (t < DMAX + 2) partial[(long)rb * (DMAX + 2) + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+}
+
+// out[c] = sum_b partial[b][c]   (fixed order)
+__global__ __launch_bounds__(256) void sum_columns_kernel(const double *__restrict__ partial, long nb, int nc, double *out)
+{
+    __shared__ double ws[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
+    for (long b = threadIdx.x; b < nb; b += 256) s += partial[b * nc + c];
+    s = wave_sum_p(s);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// out_dev[0..dmax+1] (layout above); returns the DMAX used so the caller can index T
+int launch_nll_grad(const double *Kinv, int64_t ld, int64_t n, int64_t npad, int d, const double *alpha, const double *xw,
+                    double v, double *partial, double *out_dev, int *dmax_used, hipStream_t s, Profiler *prof)
+{
+    const unsigned nblk = (unsigned)(npad / 8);
+    int dm;
+    {
+        ProfScope ps(prof, s, GPX_K_QUAD, 4.0 * (double)npad * (double)npad);
+#define GPX_NG(DM)                                                                                                     \
+    dm = DM;                                                                                                           \
+    hipLaunchKernelGGL(nll_grad_kernel<DM>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)n, (long)npad, d, alpha, xw, v, partial)
+        if (d <= 2) { GPX_NG(2); }
+        else if (d <= 4) { GPX_NG(4); }
+        else if (d <= 8) { GPX_NG(8); }
+        else if (d <= 16) { GPX_NG(16); }
+        else if (d <= 32) { GPX_NG(32); }
+        else { GPX_NG(64); }
+#undef GPX_NG
+    }
+    hipLaunchKernelGGL(sum_columns_kernel, dim3((unsigned)(dm + 2)), dim3(256), 0, s, (const double *)partial, (long)nblk, dm + 2, out_dev);
+    GPX_HIP(hipGetLastError());
+    *dmax_used = dm;
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void sum_vector_kernel(const double *__restrict__ p, long n, double *out)
 {
     __shared__ double ws[4];

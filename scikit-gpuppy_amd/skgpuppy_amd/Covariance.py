@@ -46,6 +46,39 @@ class Covariance(object):
     def get_Jacobian(self, u, xi, theta):
         raise NotImplementedError
 
+    # ---- hyper-parameter maximum likelihood ("next" row f1; skgpuppy/Covariance.py:189-337) ----------------
+    def _negativeloglikelihood(self, x, t, theta):
+        raise NotImplementedError
+
+    def _d_nll_d_theta(self, x, t, theta):
+        raise NotImplementedError
+
+    def _nll_function(self, x, t):
+        # (Covariance.py:284-297)
+        def nll(theta):
+            return self._negativeloglikelihood(x, t, theta)
+        return nll
+
+    def _gradient_function(self, x, t):
+        # (Covariance.py:299-312): retried at 0.999 theta when the factorisation fails
+        def gradient(theta):
+            try:
+                gr = self._d_nll_d_theta(x, t, theta)
+            except np.linalg.LinAlgError:
+                gr = self._d_nll_d_theta(x, t, theta * 0.999)
+            return gr
+        return gradient
+
+    def ml_estimate(self, x, t):
+        """maximum-likelihood theta by L-BFGS-B with the analytic gradient (Covariance.py:314-337, which goes
+        through Utilities.minimize(method=["l_bfgs_b"]) = scipy's fmin_l_bfgs_b with default settings)."""
+        from scipy.optimize import fmin_l_bfgs_b
+        theta_start = self.get_theta(x, t)
+        func = self._nll_function(x, t)
+        fprime = self._gradient_function(x, t)
+        theta_min = fmin_l_bfgs_b(func, theta_start, bounds=None, approx_grad=False, fprime=fprime)
+        return np.array(theta_min[0])
+
 
 def _theta(theta, d):
     th = _gpx.f64(theta)
@@ -113,6 +146,47 @@ class GaussianCovariance(Covariance):
             return model.kinv()
         finally:
             model.close()
+
+    def _model_at(self, x, t, theta):
+        """device model fitted at theta, cached on (x, t, theta) identity/bytes: L-BFGS-B asks for the value and the
+        gradient at the same theta in two separate calls."""
+        from .GaussianProcess import _DeviceModel
+        xa = _gpx.f64(x)
+        ta = _gpx.f64(t)
+        th = _theta(theta, xa.shape[1]).copy()
+        key = (xa.ctypes.data if xa is x else id(x), xa.shape, ta.tobytes(), th.tobytes())
+        cached = getattr(self, "_ml_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if cached is not None:
+            cached[1].close()
+        model = _DeviceModel(xa, ta, th)
+        self._ml_cache = (key, model)
+        return model
+
+    def _negativeloglikelihood(self, x, t, theta):
+        """N/2 log 2pi + 1/2 log det K + 1/2 t^T K^-1 t on the GPU (Covariance.py:197-216); 1e20 when K cannot be
+        factored, like the reference's except branch."""
+        try:
+            model = self._model_at(x, t, theta)
+            out = ctypes.c_double()
+            _gpx.check(_gpx.lib.gpx_nll(model.handle, ctypes.byref(out)), "gpx_nll")
+            return out.value
+        except (np.linalg.LinAlgError, ValueError, ZeroDivisionError):
+            return 1.0e+20
+
+    def _d_nll_d_theta(self, x, t, theta):
+        """gradient of the NLL (Covariance.py:266-282 with the derivative Grams of :505-512, :605-657): one fused
+        pass over K^-1 on the GPU instead of 2+d derivative matrices."""
+        model = self._model_at(x, t, theta)
+        g = np.empty(len(theta))
+        _gpx.check(_gpx.lib.gpx_nll_grad(model.handle, _gpx.ptr(g)), "gpx_nll_grad")
+        return g
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_ml_cache", None)     # device handles never enter a pickle
+        return state
 
     def get_Hessian(self, u, xi, theta):
         # (Covariance.py:660-674)

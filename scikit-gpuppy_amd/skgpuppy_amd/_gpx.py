@@ -52,6 +52,8 @@ SIGNATURES = {
     "gpx_propagate_dvh": (_int, [_hp, _dp, _dp]),
     "gpx_propagate_exact": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_exact_mean": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl)]),
+    "gpx_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_nll_grad": (_int, [_hp, _dp]),
     "gpx_profile_enable": (_int, [_hp, _int]),
     "gpx_profile_reset": (_int, [_hp]),
     "gpx_profile_read": (_int, [_hp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),

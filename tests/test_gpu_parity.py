@@ -399,3 +399,49 @@ def test_sharded_fit_two_ranks_share_one_gpu(N, d):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded vs single-GPU" in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f1: hyper-parameter likelihood, gradient and ML estimate
+# ------------------------------------------------------------------------------------------------
+def test_nll_and_gradient_golden(case):
+    name, g, gp = case
+    cov = sk.GaussianCovariance()
+    k = _loose(name)
+    for tag in ("", "_p"):
+        th = g["theta" + tag + "_used"]
+        ref, refg = float(g["nll" + tag]), g["nll_grad" + tag]
+        assert cov._negativeloglikelihood(g["x"], gp.t, th) == pytest.approx(ref, rel=1e-8 * k, abs=1e-6 * k)
+        got = cov._d_nll_d_theta(g["x"], gp.t, th)
+        np.testing.assert_allclose(got, refg, rtol=1e-6 * k, atol=1e-6 * k * max(1.0, np.abs(refg).max()))
+
+
+def test_gradient_matches_finite_differences():
+    """the reference's own check (skgpuppy/tests/tests.py:611-624, tolerance 5e-1 there)."""
+    g = load_golden("n203_d3")
+    cov = sk.GaussianCovariance()
+    t = g["t_centered"]
+    th = g["theta"].copy()
+    grad = cov._d_nll_d_theta(g["x"], t, th)
+    eps = 1e-5
+    for j in range(len(th)):
+        e = np.zeros(len(th))
+        e[j] = eps
+        num = (cov._negativeloglikelihood(g["x"], t, th + e) - cov._negativeloglikelihood(g["x"], t, th - e)) / (2 * eps)
+        assert grad[j] == pytest.approx(num, rel=1e-4, abs=1e-4)
+
+
+def test_ml_estimate_readme_example():
+    """GaussianProcess(x, t, cov) without theta = the README usage (README.rst:112-116): L-BFGS-B from get_theta."""
+    g = load_golden("kat1_grid")
+    x, t = g["x"], g["ml_t_raw"]
+    cov = sk.GaussianCovariance()
+    np.testing.assert_allclose(cov.get_theta(x, t - t.mean()), g["ml_theta_start"], rtol=1e-14)
+    gp = sk.GaussianProcess(x, t, cov)
+    nll_here = cov._negativeloglikelihood(x, gp.t, gp.theta_min)
+    assert nll_here <= float(g["ml_nll"]) + 1e-4           # at least as good an optimum as the reference found
+    assert nll_here < float(g["ml_nll_start"]) - 10
+    np.testing.assert_allclose(gp.theta_min, g["ml_theta"], atol=2e-2)
+    mean, var = gp.estimate_many(g["xs"])
+    np.testing.assert_allclose(mean, g["ml_pred_mean"], atol=5e-3)
+    np.testing.assert_allclose(var, g["ml_pred_var"], atol=5e-3)

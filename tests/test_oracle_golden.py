@@ -129,3 +129,20 @@ def test_kat2_metis_known_answers():
     assert np.sqrt(code_u) < 0.0006
     for var in (va, ve):
         assert 0.0410788036621 < np.sqrt(var - code_u) < 0.0422334526251
+
+
+def test_nll_and_gradient(case):
+    """"next" row f1: likelihood and gradient of the oracle vs the reference (Covariance.py:197-216, :266-282)."""
+    name, g, gp = case
+    for tag in ("", "_p"):
+        th = g["theta" + tag + "_used"]
+        ref, refg = float(g["nll" + tag]), g["nll_grad" + tag]
+        loose = 1e-5 if name == "metis" else 1e-8
+        assert orc.nll(g["x"], gp.t, th) == pytest.approx(ref, rel=loose, abs=loose * 10)
+        np.testing.assert_allclose(orc.nll_grad(g["x"], gp.t, th), refg, rtol=max(loose, 1e-7) * 10, atol=1e-6 * max(1.0, np.abs(refg).max()))
+
+
+def test_theta_start():
+    g = load_golden("kat1_grid")
+    t = g["ml_t_raw"] - g["ml_t_raw"].mean()
+    np.testing.assert_allclose(orc.theta_start(g["x"], t), g["ml_theta_start"], rtol=1e-14)

@@ -139,6 +139,11 @@ def gp_case(GC, GP, UP, x, t, theta, xs, us, Sigmas, v_out=0.02, keep_kinv=True,
                 o["exact_u%d_S%d" % (iu, iS)] = np.array([me, ve])
                 o["exact_mean_only_u%d_S%d" % (iu, iS)] = np.float64(upe.propagate_mean(u, S))
     o["v_out"] = np.float64(v_out)
+    # "next" row f1: likelihood and gradient at this theta (and at a perturbed one), centred targets as the GP passes them
+    for tag, th in (("", np.array(theta, dtype=float)), ("_p", np.array(theta, dtype=float) * 0.9 + 0.05)):
+        o["nll" + tag] = np.float64(cov._negativeloglikelihood(x, gp.t, th))
+        o["nll_grad" + tag] = np.array(cov._d_nll_d_theta(x, gp.t, th))
+        o["theta" + tag + "_used"] = th
     return o
 
 
@@ -160,6 +165,19 @@ def main():
     c = gp_case(GC, GP, UP, xg, tg, thg, xs_g,
                 us=[[5.0, 5.0], [5.25, 4.75]],
                 Sigmas=[np.diag([0.01, 0.01]), np.diag([1.0, 2.0]), full])
+    # ML hyper-parameter fit of the README example (GaussianProcess(x, t, cov) without theta): the README draws the
+    # targets from the GP itself (README.rst:108-109); the realisation is stored explicitly (never a seed).
+    import io, contextlib
+    np.random.seed(12345)
+    t_real = GP.get_realisation(xg, GC(), thg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        gp_ml = GP(xg, np.array(t_real), GC())
+    c["ml_t_raw"] = np.array(t_real)
+    c["ml_theta"] = np.array(gp_ml.theta_min)
+    c["ml_theta_start"] = GC().get_theta(xg, np.array(t_real) - np.mean(t_real))
+    c["ml_nll"] = np.float64(GC()._negativeloglikelihood(xg, gp_ml.t, gp_ml.theta_min))
+    c["ml_nll_start"] = np.float64(GC()._negativeloglikelihood(xg, gp_ml.t, c["ml_theta_start"]))
+    c["ml_pred_mean"], c["ml_pred_var"] = gp_ml.estimate_many(xs_g)
     np.savez_compressed(os.path.join(OUT, "kat1_grid.npz"), **c)
     print("kat1_grid.npz")
 
