@@ -13,7 +13,14 @@ from .UncertaintyPropagation import (  # noqa: F401
     UncertaintyPropagationGA,
 )
 
+from .InverseUncertaintyPropagation import (  # noqa: F401,E402
+    InverseUncertaintyPropagation,
+    InverseUncertaintyPropagationApprox,
+    InverseUncertaintyPropagationNumerical,
+)
+
 __all__ = [
     "Covariance", "GaussianCovariance", "GaussianProcess", "UncertaintyPropagationGA",
     "UncertaintyPropagationApprox", "UncertaintyPropagationExact", "tracedot",
+    "InverseUncertaintyPropagation", "InverseUncertaintyPropagationApprox", "InverseUncertaintyPropagationNumerical",
 ]

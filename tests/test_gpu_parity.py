@@ -445,3 +445,24 @@ def test_ml_estimate_readme_example():
     mean, var = gp.estimate_many(g["xs"])
     np.testing.assert_allclose(mean, g["ml_pred_mean"], atol=5e-3)
     np.testing.assert_allclose(var, g["ml_pred_var"], atol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f2: inverse uncertainty propagation (callers of propagate_GA / _get_variance_dv_h / _getFactor)
+# ------------------------------------------------------------------------------------------------
+def test_inverse_uncertainty_propagation_golden():
+    g = load_golden("kat1_grid")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    u = np.array([5.25, 4.75])
+    c = np.array([4.0, 1.0])
+    sol_a = sk.InverseUncertaintyPropagationApprox(0.02, gp, u, c, 1 / c).get_best_solution()
+    np.testing.assert_allclose(sol_a, g["iup_approx"], rtol=1e-6)
+    sol_n = sk.InverseUncertaintyPropagationNumerical(0.02, gp, u, c, 1 / c,
+                                                      upga_class=sk.UncertaintyPropagationApprox).get_best_solution()
+    np.testing.assert_allclose(sol_n, g["iup_numerical"], rtol=2e-3)
+    # the reference's own assertion (skgpuppy/tests/tests.py:399-400): analytic ~ numerical
+    assert sol_n[0] == pytest.approx(sol_a[0], abs=1e-2) and sol_n[1] == pytest.approx(sol_a[1], abs=1e-3)
+    sol_c = sk.InverseUncertaintyPropagationApprox(0.02, gp, u, c, np.array([0.25, 2.0]), coestimated=[[0, 1]]).get_best_solution()
+    np.testing.assert_allclose(sol_c, g["iup_approx_coest"], rtol=1e-6)
+    # the solution really produces the requested output variance under the approximate propagation
+    assert sk.UncertaintyPropagationApprox(gp).propagate_GA(u, np.diag(sol_a))[1] == pytest.approx(0.02, abs=1e-9)

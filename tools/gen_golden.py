@@ -178,6 +178,17 @@ def main():
     c["ml_nll"] = np.float64(GC()._negativeloglikelihood(xg, gp_ml.t, gp_ml.theta_min))
     c["ml_nll_start"] = np.float64(GC()._negativeloglikelihood(xg, gp_ml.t, c["ml_theta_start"]))
     c["ml_pred_mean"], c["ml_pred_var"] = gp_ml.estimate_many(xs_g)
+    # "next" row f2: inverse uncertainty propagation on the fixed-theta grid GP (cf. skgpuppy/tests/tests.py:361-400)
+    from skgpuppy.InverseUncertaintyPropagation import (InverseUncertaintyPropagationApprox as IUPA,
+                                                        InverseUncertaintyPropagationNumerical as IUPN)
+    gp_fix = GP(xg, np.array(tg), GC(), thg.copy())
+    cvec = np.array([4.0, 1.0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        c["iup_approx"] = IUPA(0.02, gp_fix, np.array([5.25, 4.75]), cvec, 1 / cvec).get_best_solution()
+        c["iup_numerical"] = IUPN(0.02, gp_fix, np.array([5.25, 4.75]), cvec, 1 / cvec,
+                                  upga_class=UP.UncertaintyPropagationApprox).get_best_solution()
+        c["iup_approx_coest"] = IUPA(0.02, gp_fix, np.array([5.25, 4.75]), cvec, np.array([0.25, 2.0]),
+                                     coestimated=[[0, 1]]).get_best_solution()
     np.savez_compressed(os.path.join(OUT, "kat1_grid.npz"), **c)
     print("kat1_grid.npz")
 
