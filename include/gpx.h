@@ -69,6 +69,10 @@ int gpx_n(const gpx_handle *h, int64_t *n, int *d);
 int gpx_jitter_used(const gpx_handle *h, double *jitter);   /* 0.0 or 1e-5 */
 int gpx_logdet(gpx_handle *h, double *logdet);               /* log det K  (Covariance.py:189-195) */
 
+/* ---- a4 with a caller-supplied matrix: Covariance.inv_cov_matrix(x, theta, cov_matrix=K) (Covariance.py:186-187) ----
+ * K [n,n] symmetric positive definite -> Kinv_out [n,n] (Cholesky on the GPU; status > 0 = not PD); logdet_out may be NULL. */
+int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, double *logdet_out);
+
 /* ---- a6/a7: GaussianProcess.estimate_many / estimate  (skgpuppy/GaussianProcess.py:68-111) ----
  * mean_out[m] = kv alpha   (the caller adds `meant`),  var_out[m] = v + vt - kv K^-1 kv^T.
  * Never forms the M x M matrices of the reference. */

@@ -639,11 +639,8 @@ static int ensure_kinv(gpx_handle *h)
     double *K = nullptr;
     GPX_TRY(dalloc(&K, h->npad * h->npad));
     int rc = 0;
-    // Z = I ; Z <- Z L^-T = L^-T ; Kinv = Z Z^T = L^-T L^-1 (lower tiles, then mirrored)
-    if ((rc = launch_set_identity(h->Z, h->npad, h->npad, s)) ||
-        (rc = trsm_right_lt(h->Z, h->npad, h->npad, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof)) ||
-        (rc = launch_gemm_nt(h->Z, h->npad, h->Z, h->npad, K, h->npad, h->npad, h->npad, h->npad, 1.0, 0.0, 1, s, &h->prof)) ||
-        (rc = launch_symmetrize_lower(K, h->npad, h->npad, s))) {
+    // Z = L^-T (upper triangular, structured recursion) ; Kinv = Z Z^T = L^-T L^-1 (lower strips, then mirrored)
+    if ((rc = build_kinv_from_factor(h->L, h->npad, h->nblk, h->Dinv, h->Z, K, s, &h->prof))) {
         dfree(K);
         return rc;
     }
@@ -912,6 +909,56 @@ extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigm
     CHECK_H(h);
     if (!u || !Sigma || !mean) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     return exact_common(h, u, Sigma, false, mean, nullptr);
+}
+
+// ---- a4 with a caller-supplied matrix: Covariance.inv_cov_matrix(x, theta, cov_matrix=K) = inv(K)
+// (skgpuppy/Covariance.py:186-187).  K must be symmetric positive definite (it is a covariance matrix); it is
+// Cholesky-factored on the GPU, status > 0 when it is not.
+__global__ __launch_bounds__(256) void pad_copy_kernel(const double *K, long n, double *L, long npad)
+{
+    const long i = blockIdx.x;
+    for (long j = threadIdx.x; j < npad; j += 256)
+        L[i * npad + j] = (i < n && j < n) ? K[i * n + j] : ((i == j) ? 1.0 : 0.0);
+}
+
+extern "C" int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, double *logdet_out)
+{
+    GPX_TRY(require_device());
+    if (!K || !Kinv_out || n < 1) { gpx_set_error("gpx_spd_inverse: bad arguments"); return GPX_ERR_BAD_ARG; }
+    const int64_t npad = round_up(n, TILE), nblk = npad / TILE;
+    hipStream_t s = nullptr;
+    double *Kd = nullptr, *L = nullptr, *Dinv = nullptr, *diag = nullptr, *Z = nullptr, *Ki = nullptr;
+    int *info = nullptr;
+    int rc = 0, info_h = 0;
+    double ld_h = 0.0;
+    hipError_t e = hipSuccess;
+    do {
+        if ((rc = dalloc(&Kd, n * n)) || (rc = dalloc(&L, npad * npad)) || (rc = dalloc(&Dinv, nblk * (int64_t)TILE * TILE)) ||
+            (rc = dalloc(&diag, npad + 8)) || (rc = dalloc(&Z, npad * npad)) || (rc = dalloc(&Ki, npad * npad)))
+            break;
+        if ((e = hipMalloc((void **)&info, sizeof(int))) != hipSuccess) break;
+        if ((e = hipMemsetAsync(info, 0, sizeof(int), s)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(Kd, K, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)npad), dim3(256), 0, s, (const double *)Kd, (long)n, L, (long)npad);
+        if ((rc = chol_factor(L, npad, nblk, Dinv, diag, info, s, nullptr, nullptr, nullptr))) break;
+        if ((e = hipMemcpyAsync(&info_h, info, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
+        if (info_h > 0) { gpx_set_error("matrix not positive definite (leading minor %d)", info_h); rc = info_h; break; }
+        if ((rc = build_kinv_from_factor(L, npad, nblk, Dinv, Z, Ki, s, nullptr))) break;
+        if (logdet_out) {
+            if ((rc = launch_logdet(diag, n, diag + npad, s))) break;
+            if ((e = hipMemcpyAsync(&ld_h, diag + npad, sizeof(double), hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        }
+        if ((e = hipMemcpy2DAsync(Kinv_out, sizeof(double) * n, Ki, sizeof(double) * npad, sizeof(double) * n, n, hipMemcpyDefault, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    dfree(Kd); dfree(L); dfree(Dinv); dfree(diag); dfree(Z); dfree(Ki);
+    if (info) (void)hipFree(info);
+    if (rc) return rc;
+    if (e != hipSuccess) { gpx_set_error("gpx_spd_inverse: %s", hipGetErrorString(e)); return GPX_ERR_HIP; }
+    if (logdet_out) *logdet_out = ld_h;
+    return 0;
 }
 
 // ---- "next" row f1: negative log likelihood and its gradient at the handle's theta ----------------------------------

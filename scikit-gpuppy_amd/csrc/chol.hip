@@ -275,6 +275,44 @@ int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t
     return trsm_right_lt(Z, ldz, rows, L, ldl, Dinv, cm, c1, s, prof);
 }
 
+// Z[0:c1*128, c0*128:c1*128) <- columns c0..c1 of L^-T, given that Z started as the identity and the columns left of
+// c0 are done.  L^-T is upper triangular, so only the rows above the column range carry data: a third of the flops of
+// the general TRSM on an N x N right-hand side.
+static int trtri_upper_rec(double *Z, int64_t ldz, const double *L, int64_t ldl, const double *Dinv, int64_t c0, int64_t c1,
+                           hipStream_t s, Profiler *prof)
+{
+    const int64_t nb = c1 - c0;
+    if (nb <= 0) return 0;
+    if (nb == 1) {
+        double *Zc = Z + c0 * TILE;
+        return launch_gemm_nt(Zc, ldz, Dinv + c0 * (int64_t)TILE * TILE, TILE, Zc, ldz, c1 * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof);
+    }
+    const int64_t h = split_point(nb), cm = c0 + h;
+    GPX_TRY(trtri_upper_rec(Z, ldz, L, ldl, Dinv, c0, cm, s, prof));
+    GPX_TRY(launch_gemm_nt(Z + c0 * TILE, ldz, L + (cm * TILE) * ldl + c0 * TILE, ldl, Z + cm * TILE, ldz, cm * TILE,
+                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof));
+    return trtri_upper_rec(Z, ldz, L, ldl, Dinv, cm, c1, s, prof);
+}
+
+// Kinv = L^-T L^-1 from the factor: Z (scratch, npad x npad) = L^-T, then Kinv[i,j] = sum_{k >= i} Z[i,k] Z[j,k] for the
+// lower triangle in row strips of 1024 (the k range of a strip starts at its first row), mirrored to the upper one.
+int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
+                           hipStream_t s, Profiler *prof)
+{
+    const int64_t npad = nblk * TILE;
+    GPX_TRY(launch_set_identity(Z, npad, npad, s));
+    GPX_TRY(trtri_upper_rec(Z, npad, L, ld, Dinv, 0, nblk, s, prof));
+    const int64_t SB = 8;
+    for (int64_t s0 = 0; s0 < nblk; s0 += SB) {
+        const int64_t s1 = std::min<int64_t>(s0 + SB, nblk);
+        const double *A = Z + (s0 * TILE) * npad + s0 * TILE;    // rows of the strip, k from the strip's first row
+        const double *B = Z + s0 * TILE;                          // rows 0..s1, same k range
+        GPX_TRY(launch_gemm_nt(A, npad, B, npad, Kinv + (s0 * TILE) * npad, npad, (s1 - s0) * TILE, s1 * TILE,
+                               npad - s0 * TILE, 1.0, 0.0, 0, s, prof));
+    }
+    return launch_symmetrize_lower(Kinv, npad, npad, s);
+}
+
 static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv, double *diagL, int *info_dev,
                     hipStream_t s, Profiler *prof)
 {

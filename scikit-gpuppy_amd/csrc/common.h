@@ -119,6 +119,8 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
+int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
+                           hipStream_t s, Profiler *prof);
 int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
                  double *scratch, hipStream_t s, Profiler *prof);
 int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,

@@ -138,7 +138,12 @@ class GaussianCovariance(Covariance):
         """K^-1 (Covariance.py:167-187).  The reference LU-inverts; here K is Cholesky-factored on the GPU
         (with the reference's +1e-5 I retry on a non-PD pivot) and K^-1 = L^-T L^-1."""
         if cov_matrix is not None:
-            raise NotImplementedError("inverting a caller-supplied matrix is outside the accelerated path")
+            K = _gpx.f64(cov_matrix)
+            if K.ndim != 2 or K.shape[0] != K.shape[1]:
+                raise ValueError("cov_matrix must be square")
+            out = np.empty_like(K)
+            _gpx.check(_gpx.lib.gpx_spd_inverse(_gpx.ptr(K), K.shape[0], _gpx.ptr(out), None), "gpx_spd_inverse")
+            return out
         from .GaussianProcess import _DeviceModel
         xa = _gpx.f64(x)
         model = _DeviceModel(xa, np.zeros(xa.shape[0]), _theta(theta, xa.shape[1]))

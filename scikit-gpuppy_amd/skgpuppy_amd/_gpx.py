@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpx_n": (_int, [_hp, ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
     "gpx_jitter_used": (_int, [_hp, ctypes.POINTER(_dbl)]),
     "gpx_logdet": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_spd_inverse": (_int, [_dp, _i64, _dp, ctypes.POINTER(_dbl)]),
     "gpx_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
     "gpx_alpha": (_int, [_hp, _dp]),
     "gpx_kinv": (_int, [_hp, _dp]),

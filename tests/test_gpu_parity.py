@@ -466,3 +466,32 @@ def test_inverse_uncertainty_propagation_golden():
     np.testing.assert_allclose(sol_c, g["iup_approx_coest"], rtol=1e-6)
     # the solution really produces the requested output variance under the approximate propagation
     assert sk.UncertaintyPropagationApprox(gp).propagate_GA(u, np.diag(sol_a))[1] == pytest.approx(0.02, abs=1e-9)
+
+
+def test_inv_cov_matrix_with_supplied_matrix():
+    """Covariance.inv_cov_matrix(x, theta, cov_matrix=K) = inv(K)  (skgpuppy/Covariance.py:186-187)."""
+    g = load_golden("n256_d8")
+    cov = sk.GaussianCovariance()
+    K = cov.cov_matrix(g["x"], g["theta"])
+    Kinv = cov.inv_cov_matrix(g["x"], g["theta"], cov_matrix=K)
+    np.testing.assert_allclose(Kinv, g["Kinv"], rtol=0, atol=1e-7 * np.abs(g["Kinv"]).max())
+    Kinv2 = cov.inv_cov_matrix(g["x"], g["theta"])
+    np.testing.assert_allclose(Kinv2, g["Kinv"], rtol=0, atol=1e-7 * np.abs(g["Kinv"]).max())
+    with pytest.raises(np.linalg.LinAlgError):
+        cov.inv_cov_matrix(g["x"], g["theta"], cov_matrix=-np.eye(5))
+
+
+def test_kinv_identity_at_scale():
+    """K^-1 from the structured trtri + strip SYRK: K Kinv = I on sampled rows at N = 4096."""
+    x, t, xs, theta = _recipe(4096, 4, 8)
+    cov = sk.GaussianCovariance()
+    gp = sk.GaussianProcess(x, t, cov, theta.copy())
+    Kinv = gp.Kinv
+    rows = np.random.RandomState(2).choice(4096, 64, replace=False)
+    Krows = cov.cov_matrix_ij(x[rows], x, theta)
+    Krows[np.arange(64), rows] += 0.01
+    P = Krows.dot(Kinv)
+    E = np.zeros_like(P)
+    E[np.arange(64), rows] = 1.0
+    assert np.abs(P - E).max() < 1e-8
+    np.testing.assert_array_equal(Kinv, Kinv.T)
