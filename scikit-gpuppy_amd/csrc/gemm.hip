@@ -296,7 +296,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
 }
 
 // ---- micro-benchmark: issue rate of v_mfma_f64_16x16x4_f64 (roofline denominator check) ----------
-__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double *out, int iters)
+__global__ __launch_bounds__(256, 2) void mfma_f64_rate_kernel(double *out, int iters)
 {
     v4d acc[8];
 #pragma unroll
@@ -344,7 +344,7 @@ extern "C" int gpx_bench_mfma_f64(int iters, double *tflops)
 // ---- diagnostic: cycles per instruction and the clock the chip holds under an fp64 MFMA / VALU load ----
 // mode 0: every wave issues MFMA f64; mode 1: every wave issues packed-free VALU v_fma_f64;
 // mode 2: even waves MFMA, odd waves VALU (do the two pipes add up, or is the chip power-bound?)
-__global__ __launch_bounds__(256) void fp64_pipe_kernel(double *out, unsigned long long *stamps, int iters, int mode)
+__global__ __launch_bounds__(256, 2) void fp64_pipe_kernel(double *out, unsigned long long *stamps, int iters, int mode)
 {
     const int wave = threadIdx.x >> 6;
     const bool use_mfma = (mode == 0) || (mode == 2 && (wave & 1) == 0);
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void fp64_pipe_kernel(double *out, unsigned lo
 
 // mode 10+k: MFMA f64 with 2^k independent accumulators per wave (k = 0..5): issue interval vs dependent latency
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_chain_kernel(double *out, unsigned long long *stamps, int iters)
+__global__ __launch_bounds__(256, 2) void mfma_chain_kernel(double *out, unsigned long long *stamps, int iters)
 {
     v4d acc[NACC];
 #pragma unroll
