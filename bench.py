@@ -124,23 +124,25 @@ def run_single(args):
     lib = _gpx.lib
     vp = lambda tt: ctypes.c_void_p(tt.data_ptr())  # noqa: E731
 
-    prof = {k: [0, 0.0, 0.0] for k in range(7)}
+    NCLS = len(_gpx.KERNEL_CLASS_NAMES)
+    prof = {k: [0, 0.0, 0.0] for k in range(NCLS)}
     t_fit = [0.0]
     t_pred = [0.0]
 
-    def step(timed):
+    def step(timed, clock=True):
         h = ctypes.c_void_p()
         a = time.perf_counter()
         _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "gpx_fit")
         b = time.perf_counter()
         if timed:
-            lib.gpx_profile_enable(h, 1)
+            lib.gpx_profile_enable(h, int(os.environ["GPX_PROFILE"]))
         _gpx.check(lib.gpx_predict(h, vp(xsd), M, vp(mean_d), vp(var_d)), "gpx_predict")
         c = time.perf_counter()
         if timed:
-            t_fit[0] += b - a
-            t_pred[0] += c - b
-            for k in range(7):
+            if clock:
+                t_fit[0] += b - a
+                t_pred[0] += c - b
+            for k in (range(NCLS) if os.environ["GPX_PROFILE"] == "2" else (_gpx.K_GEMM,)):
                 n_, ms_, w_ = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
                 lib.gpx_profile_read(h, k, ctypes.byref(n_), ctypes.byref(ms_), ctypes.byref(w_))
                 prof[k][0] += n_.value
@@ -148,8 +150,10 @@ def run_single(args):
                 prof[k][2] += w_.value
         lib.gpx_free(h)
 
-    # fit-side kernels are profiled through a process-wide switch so that gpx_fit itself is covered
-    os.environ["GPX_PROFILE"] = "1"
+    # Timed region: only the dominant kernel (128x128-tile GEMM launches, ~106 per step) is bracketed with HIP events
+    # on its stream (level 1; bracketing all ~1100 launches of a step costs ~9 % of the step).  The per-class table is
+    # taken afterwards from ONE extra, untimed step at level 2.  The switch is process wide so gpx_fit is covered.
+    os.environ["GPX_PROFILE"] = os.environ.get("GPX_BENCH_PROFILE", "1")
     for _ in range(args.warmup):
         step(False)
     torch.cuda.synchronize()
@@ -161,6 +165,16 @@ def run_single(args):
 
     value = (N + M) * args.steps / elapsed
     g_n, g_ms, g_flops = prof[_gpx.K_GEMM]
+    table_prof = {k: list(v) for k, v in prof.items()}
+    if os.environ["GPX_PROFILE"] != "2":
+        for k in prof:
+            prof[k] = [0, 0.0, 0.0]
+        os.environ["GPX_PROFILE"] = "2"
+        step(True, clock=False)
+        torch.cuda.synchronize()
+        table_prof, table_steps = prof, 1
+    else:
+        table_steps = args.steps
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     # known-good reference on the same box: the vendor DGEMM (rocBLAS through torch) on an 8192^3 NT product
     a_ = torch.randn(8192, 8192, dtype=torch.float64, device=dev)
@@ -214,9 +228,9 @@ def run_single(args):
             "flops_per_step": g_flops / max(1, args.steps),
             "vendor_dgemm_8192_tflops_same_box": vendor_tf,
         },
-        "kernel_classes": {
-            _gpx.KERNEL_CLASS_NAMES[k]: {"launches": prof[k][0] / args.steps, "ms": prof[k][1] / args.steps,
-                                         "work": prof[k][2] / args.steps} for k in range(7) if prof[k][0]},
+        "kernel_classes_from_untimed_profiling_step": {
+            _gpx.KERNEL_CLASS_NAMES[k]: {"launches": table_prof[k][0] / table_steps, "ms": table_prof[k][1] / table_steps,
+                                         "work": table_prof[k][2] / table_steps} for k in range(NCLS) if table_prof[k][0]},
     }
     if not args.no_propagate:
         out["propagate"] = propagate_section(lib, _gpx, vp, xd, td, th, N, d)

@@ -119,15 +119,18 @@ int gpx_nll_grad(gpx_handle *h, double *grad_out);
  * EXACT) or bytes (others) as defined in DESIGN.md. */
 enum {
     GPX_K_GRAM = 0,      /* Gram / cross-covariance assembly             (bytes) */
-    GPX_K_GEMM = 1,      /* fp64 MFMA GEMM/SYRK/TRSM-leaf tiles           (flops) */
+    GPX_K_GEMM = 1,      /* fp64 MFMA GEMM/SYRK/TRSM, 128x128 tiles (dominant) (flops) */
     GPX_K_POTRF_LEAF = 2,/* 128x128 diagonal-block factor + inverse       (flops) */
     GPX_K_TRSV = 3,      /* blocked triangular solves for alpha           (bytes) */
     GPX_K_REDUCE = 4,    /* predictive mean/variance row reductions       (bytes) */
     GPX_K_QUAD = 5,      /* Kinv x V pass of propagate (approx)           (bytes) */
     GPX_K_EXACT = 6,     /* Girard l_i / L_ij double sum                  (flops) */
-    GPX_K_COUNT = 7
+    GPX_K_GEMM_SMALL = 7,/* the same GEMM kernel in its 64/32-row tile variants (critical-path products) */
+    GPX_K_COUNT = 8
 };
-int gpx_profile_enable(gpx_handle *h, int on);
+/* level 0 = off, 1 = bracket only the dominant kernel (GPX_K_GEMM: 128x128-tile launches), 2 = every class.
+ * Environment variable GPX_PROFILE=<level> sets the level of handles at creation (covers gpx_fit itself). */
+int gpx_profile_enable(gpx_handle *h, int level);
 int gpx_profile_reset(gpx_handle *h);
 int gpx_profile_read(gpx_handle *h, int kernel_class, int64_t *launches, double *total_ms, double *total_work);
 

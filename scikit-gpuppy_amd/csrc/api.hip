@@ -377,8 +377,9 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
                 else m_bulk[c >> 5] |= 1u << (c & 31);
             }
             if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess)
+                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
                 masked = true;
+            }
             else {
                 (void)hipGetLastError();
                 if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
@@ -392,7 +393,7 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
         }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };
-    if (const char *pe = getenv("GPX_PROFILE")) h->prof.on = (pe[0] == '1');   // covers the kernels of gpx_fit itself
+    if (const char *pe = getenv("GPX_PROFILE")) h->prof.level = atoi(pe);   // covers the kernels of gpx_fit itself
 
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
@@ -485,8 +486,9 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
                 else m_bulk[c >> 5] |= 1u << (c & 31);
             }
             if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess)
+                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
                 masked = true;
+            }
             else {
                 (void)hipGetLastError();
                 if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
@@ -500,7 +502,7 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
         }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };
-    if (const char *pe = getenv("GPX_PROFILE")) h->prof.on = (pe[0] == '1');   // covers the kernels of gpx_fit itself
+    if (const char *pe = getenv("GPX_PROFILE")) h->prof.level = atoi(pe);   // covers the kernels of gpx_fit itself
 
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
@@ -1012,7 +1014,7 @@ extern "C" int gpx_nll_grad(gpx_handle *h, double *grad_out)
 extern "C" int gpx_profile_enable(gpx_handle *h, int on)
 {
     if (!h) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; }
-    h->prof.on = on != 0;
+    h->prof.level = on < 0 ? 0 : on;
     return 0;
 }
 extern "C" int gpx_profile_reset(gpx_handle *h)

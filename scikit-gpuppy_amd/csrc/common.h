@@ -35,7 +35,7 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 
 // ---- per-kernel-class event profiler ---------------------------------------------------------
 struct Profiler {
-    bool on = false;
+    int level = 0;   // 0 off; 1 = only the dominant kernel (128x128-tile GEMM launches); 2 = every kernel class
     struct Rec { int cls; double work; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
@@ -51,8 +51,8 @@ struct Profiler {
 
 struct ProfScope {
     Profiler *p; hipStream_t s; int idx;
-    ProfScope(Profiler *p_, hipStream_t s_, int cls, double w) : p(p_), s(s_), idx(-1) {
-        if (p && p->on) idx = p->begin(s, cls, w);
+    ProfScope(Profiler *p_, hipStream_t s_, int cls, double w, int min_level = 2) : p(p_), s(s_), idx(-1) {
+        if (p && p->level >= min_level) idx = p->begin(s, cls, w);
     }
     ~ProfScope() { if (idx >= 0) p->end(s, idx); }
 };

@@ -264,7 +264,9 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         return GPX_ERR_BAD_ARG;
     }
     const double tiles = lower_only ? 0.5 * (double)(M / TILE) * (double)(M / TILE + 1) : (double)(M / TILE) * (double)(N / TILE);
-    ProfScope ps(prof, s, GPX_K_GEMM, tiles * 2.0 * TILE * TILE * (double)K);
+    // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2
+    ProfScope ps(prof, s, tiles >= SMALL_GRID_TILES ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K,
+                 tiles >= SMALL_GRID_TILES ? 1 : 2);
     const bool in_place = (C == A || C == B);   // in-place TRSM leaves: exactly one column tile per row block
     if (in_place && N != TILE) {
         gpx_set_error("launch_gemm_nt: in-place product needs N == %d", TILE);
