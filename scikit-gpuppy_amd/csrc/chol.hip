@@ -69,9 +69,8 @@ __device__ __forceinline__ void potrf128_block_step(double (&acc)[8][8], double 
     }
 }
 
-__global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, double *diag_out, int *info, int col_offset)
+__device__ __forceinline__ void potrf128_body(double *A, long ld, double *diag_out, int *info, int col_offset, double (*Ls)[TILE])
 {
-    __shared__ double Ls[2][TILE];
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     double acc[8][8];
 #pragma unroll
@@ -105,6 +104,12 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, doubl
     }
 }
 
+__global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, double *diag_out, int *info, int col_offset)
+{
+    __shared__ double Ls[2][TILE];
+    potrf128_body(A, ld, diag_out, info, col_offset, Ls);
+}
+
 // ------------------------------------------------------------------------------------------------
 // trtri128: X = L^-1 for a 128x128 lower-triangular L (row-major, ld) -> dinv[128][128] (ld 128).
 // Level 0 inverts the eight 16x16 diagonal blocks (16 lanes per block, one column each); levels 1..3
@@ -117,9 +122,8 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, doubl
 constexpr int XB = 16 * 17;                                  // doubles per packed block
 __device__ __forceinline__ int xblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * XB; }
 
-__global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld, double *dinv)
+__device__ __forceinline__ void trtri128_body(const double *L, long ld, double *dinv, double *X)
 {
-    __shared__ __attribute__((aligned(16))) double X[36 * XB];
     const int t = threadIdx.x;
     const int wave = t >> 6, lane = t & 63;
     const int fr = lane & 15, fq = lane >> 4;
@@ -229,12 +233,28 @@ __global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld,
     }
 }
 
+__global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld, double *dinv)
+{
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    trtri128_body(L, ld, dinv, X);
+}
+
+// leaf = factor + inverse in ONE launch (one fewer kernel boundary on the factorisation's critical path); the
+// factor travels from the first half to the second through global memory behind a workgroup barrier.
+__global__ __launch_bounds__(256) void potrf_trtri128_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
+                                                            int col_offset)
+{
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    potrf128_body(A, ld, diag_out, info, col_offset, reinterpret_cast<double (*)[TILE]>(X));
+    __syncthreads();
+    trtri128_body(A, ld, dinv, X);
+}
+
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
-    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, diag_out, info_dev, col_offset);
-    hipLaunchKernelGGL(trtri128_kernel, dim3(1), dim3(256), 0, s, (const double *)A, (long)ld, dinv);
+    hipLaunchKernelGGL(potrf_trtri128_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
     GPX_HIP(hipGetLastError());
     return 0;
 }

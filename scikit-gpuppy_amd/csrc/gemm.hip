@@ -120,15 +120,31 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         }                                                                                                           \
     }
 
-    v4d acc[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-
     const int nk = K / GEMM_BK;
     constexpr int NDMA = (BTM / 8 + 3) / 4 + (BTN / 8 + 3) / 4;   // LDS-DMA instructions per wave per stage
     GPX_DMA_STAGE(0, 0)
+    // C enters through the accumulators: acc0 = (beta/alpha) C, result = alpha (acc0 + A B^T).  The tile's read
+    // overlaps the first DMA stage instead of sitting, dependent, in the epilogue (matters for the K = 128..512
+    // updates on the factorisation's critical path).  accumulator register r of tile (i,j) is C[fq + 4r][fr].
+    double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
+    v4d acc[WM][WN];
+    if (beta != 0.0) {
+        const double bs = beta / alpha;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                v4d c0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c0[r] = bs * Cw[(long)(i * 16 + 4 * r) * ldc + j * 16];
+                acc[i][j] = c0;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
     if constexpr (BIG) {
         if (nk > 1) GPX_DMA_STAGE(1, 1)
         if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
@@ -214,26 +230,13 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             for (int j = 0; j < WN; ++j) gpx_acc_fence(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
         }
     }
-    // epilogue: accumulator register r of tile (i,j) is C[row = fq + 4r][col = fr] of that 16x16 tile
-    double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
-    if (beta == 0.0) {
+    // epilogue: pure stores
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
-    } else {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double *p = &Cw[(long)(i * 16 + 4 * r) * ldc + j * 16];
-                    *p = fma(alpha, acc[i][j][r], beta * (*p));
-                }
-    }
+            for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
 #ifdef GPX_GEMM_STAMP
@@ -284,7 +287,9 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                                (long)ldc, (int)K, alpha, beta);                                                       \
     } while (0)
     static const int big_mode = getenv("GPX_GEMM_BIG") ? atoi(getenv("GPX_GEMM_BIG")) : 0;
-    if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 1 && N % 256 == 0) GPX_LAUNCH(4, 8);
+    if (big_mode == 3 && !lower_only) GPX_LAUNCH(2, 4);          // experiments: force a tile shape
+    else if (big_mode == 4 && !lower_only) GPX_LAUNCH(2, 2);
+    else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 1 && N % 256 == 0) GPX_LAUNCH(4, 8);
     else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 2 && M % 256 == 0) GPX_LAUNCH(8, 4);
     else if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
