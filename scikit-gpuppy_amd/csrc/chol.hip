@@ -458,33 +458,59 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
 // One launch per 128-block step; every workgroup first forms the step's solved block from the
 // inverted diagonal block (redundantly: 16K FMA), then applies its own 128x128 off-diagonal block.
 // ------------------------------------------------------------------------------------------------
+// 128x128 tile (row-major, ld) times a 128-vector held in LDS, rows across waves: wave w owns rows 32w..32w+31, every
+// wave-instruction reads one whole 1-KiB row (lane l -> columns 2l, 2l+1), all 32 loads of a wave are issued before
+// the first use (memory-level parallelism), and the 32 per-lane partial sums are reduced by a transposing butterfly
+// (32 shuffles instead of 32 x 6).  Returns, on lanes with (lane & 1) == 0, the finished dot product of row
+//   row_of_lane = 32w + 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1   (b_i = bit i of the lane id).
+__device__ __forceinline__ double tile_matvec_rows(const double *tile, long ld, const double *vec_lds, int wave, int lane)
+{
+    v2d lt[32];
+    const double *base = tile + (long)(32 * wave) * ld + 2 * lane;
+#pragma unroll
+    for (int q = 0; q < 32; ++q) lt[q] = *reinterpret_cast<const v2d *>(base + (long)q * ld);
+    const v2d vv = *reinterpret_cast<const v2d *>(vec_lds + 2 * lane);
+    double p[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) p[q] = fma(lt[q].x, vv.x, lt[q].y * vv.y);
+#define GPX_BFLY(HALF, BIT)                                                        \
+    _Pragma("unroll") for (int q = 0; q < HALF; ++q) {                             \
+        const bool up = (lane >> BIT) & 1;                                         \
+        const double send = up ? p[q] : p[q + HALF];                               \
+        const double keep = up ? p[q + HALF] : p[q];                               \
+        p[q] = keep + __shfl_xor(send, 1 << BIT);                                  \
+    }
+    GPX_BFLY(16, 5)
+    GPX_BFLY(8, 4)
+    GPX_BFLY(4, 3)
+    GPX_BFLY(2, 2)
+    GPX_BFLY(1, 1)
+#undef GPX_BFLY
+    return p[0] + __shfl_xor(p[0], 1);
+}
+__device__ __forceinline__ int butterfly_row(int wave, int lane)
+{
+    return 32 * wave + 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
+}
+
 // forward step k: yk = Dinv_k r_k ; r_{k+1+bid} -= L[k+1+bid, k] yk   (block 0 also stores yk)
 __global__ __launch_bounds__(256) void trsv_fwd_step(const double *L, long ld, const double *Dinv, int k, double *r,
                                                     double *y)
 {
-    __shared__ double rk[TILE], yk[TILE];
-    const int t = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double rk[TILE], yk[TILE];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     if (t < TILE) rk[t] = r[(long)k * TILE + t];
     __syncthreads();
-    {   // yk[i] = sum_j Dinv_k[i][j] rk[j], j <= i ; two threads per row
-        const int i = t >> 1, half = t & 1;
-        const double *Di = Dinv + (long)k * TILE * TILE + (long)i * TILE;
-        double s = 0.0;
-        for (int j = half; j <= i; j += 2) s = fma(Di[j], rk[j], s);
-        s += __shfl_xor(s, 1);
-        if (half == 0) yk[i] = s;
+    {
+        const double s = tile_matvec_rows(Dinv + (long)k * TILE * TILE, TILE, rk, wave, lane);   // zeros above the diagonal
+        if ((lane & 1) == 0) yk[butterfly_row(wave, lane)] = s;
     }
     __syncthreads();
     if (blockIdx.x == 0 && t < TILE) y[(long)k * TILE + t] = yk[t];
-    const long rb = (long)k + 1 + blockIdx.x;   // block row to update (gridDim.x = nblk - k - 1; may be 0 -> no blocks)
+    const long rb = (long)k + 1 + blockIdx.x;   // block row to update (gridDim.x = nblk - k - 1)
     {
-        const int i = t >> 1, half = t & 1;
-        const double *Li = L + (rb * TILE + i) * ld + (long)k * TILE + 64 * half;
-        double s = 0.0;
-#pragma unroll 8
-        for (int j = 0; j < 64; ++j) s = fma(Li[j], yk[64 * half + j], s);
-        s += __shfl_xor(s, 1);
-        if (half == 0) r[rb * TILE + i] -= s;
+        const double s = tile_matvec_rows(L + (rb * TILE) * ld + (long)k * TILE, ld, yk, wave, lane);
+        if ((lane & 1) == 0) r[rb * TILE + butterfly_row(wave, lane)] -= s;
     }
 }
 
@@ -507,34 +533,42 @@ __global__ __launch_bounds__(256) void trsv_diag_only(const double *Dinv, int k,
     if (half == 0) y[(long)k * TILE + i] = s;
 }
 
+// transposed 128x128 tile times a 128-vector in LDS, columns across threads: thread (col, half) sums 64 rows of its
+// column; every wave-instruction reads 512 contiguous bytes of one row; all 64 loads are issued before the first use.
+__device__ __forceinline__ double tile_matvecT_cols(const double *tile, long ld, const double *vec_lds, int col, int half)
+{
+    double lt[64];
+    const double *base = tile + (long)(64 * half) * ld + col;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) lt[q] = base[(long)q * ld];
+    const double *vv = vec_lds + 64 * half;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; q += 2) {
+        s0 = fma(lt[q], vv[q], s0);
+        s1 = fma(lt[q + 1], vv[q + 1], s1);
+    }
+    return s0 + s1;
+}
+
 // backward step k: ak = Dinv_k^T s_k ; s_{cb} -= L[k, cb]^T ak  for column block cb = blockIdx.x < k
 __global__ __launch_bounds__(256) void trsv_bwd_step(const double *L, long ld, const double *Dinv, int k, double *sv,
                                                     double *a)
 {
     __shared__ double sk[TILE], ak[TILE];
     __shared__ double part[2][TILE];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, col = t & 127, half = t >> 7;
     if (t < TILE) sk[t] = sv[(long)k * TILE + t];
     __syncthreads();
-    {
-        const int i = t >> 1, half = t & 1;
-        const double *D = Dinv + (long)k * TILE * TILE;
-        double s = 0.0;
-        for (int j = i + half; j < TILE; j += 2) s = fma(D[(long)j * TILE + i], sk[j], s);
-        s += __shfl_xor(s, 1);
-        if (half == 0) ak[i] = s;
-    }
+    part[half][col] = tile_matvecT_cols(Dinv + (long)k * TILE * TILE, TILE, sk, col, half);   // zeros above the diagonal
+    __syncthreads();
+    if (t < TILE) ak[t] = part[0][t] + part[1][t];
     __syncthreads();
     if (blockIdx.x == 0 && t < TILE) a[(long)k * TILE + t] = ak[t];
-    const long cb = blockIdx.x;                 // gridDim.x = k column blocks (k >= 1 when launched through this path)
-    {   // s_cb[j] -= sum_i L[k*128+i][cb*128+j] ak[i]; thread (j = t&127, half = t>>7) sums 64 rows, coalesced in j
-        const int j = t & 127, half = t >> 7;
-        const double *Lc = L + ((long)k * TILE + 64 * half) * ld + cb * TILE + j;
-        double s = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) s = fma(Lc[(long)i * ld], ak[64 * half + i], s);
-        part[half][j] = s;
-    }
+    const long cb = blockIdx.x;                 // gridDim.x = k column blocks
+    const double s = tile_matvecT_cols(L + ((long)k * TILE) * ld + cb * TILE, ld, ak, col, half);
+    __syncthreads();
+    part[half][col] = s;
     __syncthreads();
     if (t < TILE) sv[cb * TILE + t] -= part[0][t] + part[1][t];
 }
