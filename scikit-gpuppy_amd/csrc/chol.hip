@@ -364,24 +364,31 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
 constexpr int64_t CHOL_NBP = 8;
 
 // factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
-int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
-                      int *info_dev, hipStream_t s, Profiler *prof)
+// steps j in [j0,j1) of the diagonal square [B0,B1): leaf (factor + inverse), in-place TRSM leaf of the rows below
+// inside the square, rank-128 update of the square's remaining columns -- the latency-bound chain of small kernels
+static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
+                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof)
 {
-    // (a) the (B1-B0)-block diagonal square, 128 columns at a time: only this latency-bound chain of small
-    //     kernels is serial; (b) everything below it in ONE recursive TRSM made of large GEMMs.
-    const int64_t nblk = B1;
-    for (int64_t j = B0; j < B1; ++j) {
+    (void)B0;
+    for (int64_t j = j0; j < j1; ++j) {
         GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
                                   info_dev, (int)(j * TILE), s, prof));
-        const int64_t rows_below = nblk - (j + 1);
+        const int64_t rows_below = B1 - (j + 1);
         if (rows_below <= 0) continue;
         double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
         GPX_TRY(launch_gemm_nt(Z, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Z, ld, rows_below * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof));
-        const int64_t cols_rest = B1 - (j + 1);
-        if (cols_rest > 0)                                                  // rest of the panel: C -= Z Z[0:cols]^T
-            GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
-                                   cols_rest * TILE, TILE, -1.0, 1.0, 0, s, prof));
+        GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
+                               rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
     }
+    return 0;
+}
+
+// factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied):
+// (a) the diagonal square, 128 columns at a time; (b) everything below it in ONE recursive TRSM made of large GEMMs
+int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
+                      int *info_dev, hipStream_t s, Profiler *prof)
+{
+    GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof));
     if (nblk_all > B1)
         GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk_all - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
     return 0;
@@ -406,30 +413,38 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     int rc = 0;
     auto run = [&]() -> int {
         // Per outer panel p the main stream runs, in order:
-        //   tall TRSM of panel p (rows below its diagonal square; large GEMMs, whole machine)
-        //   narrow update of panel p+1's columns               -> event: the side stream may start
+        //   TRSM of rows [B1,B2) of panel p + update of panel p+1's diagonal square  -> event: the side stream starts
+        //   TRSM of the remaining rows of panel p, update of the remaining rows of panel p+1's columns,
         //   bulk SYRK of everything right of panel p+1
         // and the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, a few
-        // CUs, pure latency) underneath the bulk SYRK.
+        // CUs, pure latency) underneath all of that.
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
-        GPX_TRY(chol_panel_factor(L, ld, std::min<int64_t>(CHOL_NBP, nblk), 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL,
+        GPX_TRY(chol_square_steps(L, ld, 0, std::min<int64_t>(CHOL_NBP, nblk), 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL,
                                   info_dev, s_pan, prof));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = p * CHOL_NBP, B1 = std::min<int64_t>(B0 + CHOL_NBP, nblk), B2 = std::min<int64_t>(B1 + CHOL_NBP, nblk);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) break;
-            GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const int64_t K = (B1 - B0) * TILE;
-            const double *Pn = L + (B1 * TILE) * ld + B0 * TILE;           // panel p, rows >= B1
-            GPX_TRY(launch_gemm_nt(Pn, ld, Pn, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (nblk - B1) * TILE, (B2 - B1) * TILE, K,
+            // (1) top slice first: only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next
+            //     chain, so they are solved / updated before anything else and the side stream starts early
+            GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (B2 - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
+            const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
+            GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
                                    -1.0, 1.0, 0, s, prof));
             GPX_HIP(hipEventRecord(ev_next[p], s));
-            // bulk SYRK first in host order (its launch must not queue behind the ~30 small launches below);
-            // it runs on the bulk stream, whose CU mask leaves a few CUs to the side stream
+            // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
+            // so neither stream starves while the other's launches are being queued
+            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof));
             if (B2 < nblk) {
+                // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
+                GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
+                GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
+                                       K, -1.0, 1.0, 0, s, prof));
                 if (s_bulk != s) GPX_HIP(hipStreamWaitEvent(s_bulk, ev_next[p], 0));
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                        (nblk - B2) * TILE, K, -1.0, 1.0, 1, s_bulk, prof));
@@ -438,8 +453,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
                 }
             }
-            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_panel_factor(L, ld, B2, B1, B2, Dinv, diagL, info_dev, s_pan, prof));   // diagonal square only
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
         return 0;
