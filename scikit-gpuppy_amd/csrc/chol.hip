@@ -245,6 +245,9 @@ __global__ __launch_bounds__(256) void potrf_trtri128_kernel(double *A, long ld,
                                                             int col_offset)
 {
     __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    // the leaf is the latency-critical kernel of the factorisation and usually shares its CU with bulk GEMM waves:
+    // take issue priority over them
+    __builtin_amdgcn_s_setprio(3);
     potrf128_body(A, ld, diag_out, info, col_offset, reinterpret_cast<double (*)[TILE]>(X));
     __syncthreads();
     trtri128_body(A, ld, dinv, X);

@@ -79,3 +79,35 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_jacobian_hessian_match_finite_differences():
+    """the reference's own checks (skgpuppy/tests/tests.py:1310-1320, tolerance 1e-2 there): analytic Jacobian and
+    Hessian of the kernel w.r.t. its second argument against central differences (host-side accessors)."""
+    cov = skgpuppy_amd.GaussianCovariance()
+    th = np.log(np.array([1.7, 0.02, 0.3, 0.08, 1.1]))
+    rng = np.random.RandomState(4)
+    u, xi = rng.randn(3), rng.randn(3)
+    k = lambda z: cov(u, z, th)            # noqa: E731
+    eps = 1e-5
+    J = cov.get_Jacobian(u, xi, th)
+    H = cov.get_Hessian(u, xi, th)
+    for a in range(3):
+        e = np.zeros(3)
+        e[a] = eps
+        # the reference's Jacobian is d/d(xi) (sign note at Covariance.py:687)
+        assert J[a, 0] == pytest.approx((k(xi + e) - k(xi - e)) / (2 * eps), rel=1e-6, abs=1e-9)
+        for b in range(3):
+            f = np.zeros(3)
+            f[b] = eps
+            num = (k(xi + e + f) - k(xi + e - f) - k(xi - e + f) + k(xi - e - f)) / (4 * eps * eps)
+            assert H[a, b] == pytest.approx(num, rel=1e-4, abs=1e-6)
+
+
+def test_get_theta_matches_reference_formula():
+    cov = skgpuppy_amd.GaussianCovariance()
+    rng = np.random.RandomState(1)
+    x, t = rng.uniform(-2, 5, (40, 3)), rng.randn(40)
+    th = cov.get_theta(x, t)
+    assert th[0] == pytest.approx(np.log(np.var(t))) and th[1] == pytest.approx(np.log(np.var(t) / 4))
+    np.testing.assert_allclose(th[2:], -2 * np.log((x.max(0) - x.min(0)) / 2.0))
