@@ -113,6 +113,23 @@ int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *
 int gpx_nll(gpx_handle *h, double *nll);
 int gpx_nll_grad(gpx_handle *h, double *grad_out);
 
+/* ---- "next" row f3: Snelson sparse pseudo-input GP (SPGPCovariance, skgpuppy/Covariance.py:692-1019) ----
+ * theta = [log v, log vt, log w_1..d] (the GaussianCovariance part of the reference's theta), xb = the m x d
+ * pseudo-inputs (the tail of the reference's theta, reshaped).  The fit keeps K_NM, chol(K_M + 1e-5 I),
+ * Lambda = diag(K_N - Q_N) + vt and chol(B + 1e-5 I), B = K_M + K_MN Lambda^-1 K_NM, on the device: O(N M^2), no N x N
+ * matrix.  gpx_spgp_predict returns what GaussianProcess.estimate_many (GaussianProcess.py:68-80) computes with
+ * cov = SPGPCovariance: mean = Q_*N Kinv t (WITHOUT meant), var = v + vt - diag(Q_*N Kinv Q_N*), Kinv the Woodbury
+ * inverse of :835-863.  gpx_spgp_nll is Snelson's likelihood (:981-1019, jitter 1e-6).  gpx_spgp_dense / _cross
+ * materialise cov_matrix(x) (which=0), inv_cov_matrix(x) (which=1) and cov_matrix_ij(xi,xj) for the accessors. */
+typedef struct gpx_spgp gpx_spgp;
+int gpx_spgp_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, const double *xb,
+                 int64_t m, gpx_spgp **out);
+void gpx_spgp_free(gpx_spgp *h);
+int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, double *mean /* [ms] */, double *var /* [ms] */);
+int gpx_spgp_nll(gpx_spgp *h, double *nll);
+int gpx_spgp_dense(gpx_spgp *h, int which, double *out /* [n,n] */);
+int gpx_spgp_cross(gpx_spgp *h, const double *xi, int64_t n1, const double *xj, int64_t n2, double *out /* [n1,n2] */);
+
 /* ---- measurement: per-kernel-class GPU timings taken with HIP events on the handle's stream ----
  * gpx_profile_enable(h,1) brackets every launch of the listed kernel classes with an event pair;
  * gpx_profile_read sums them (it synchronises the stream).  work = algorithmic flops (GEMM, POTRF,

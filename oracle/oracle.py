@@ -324,3 +324,99 @@ def exact_propagate(gp, u, Sigma):
     Kinv = _c(gp.Kinv)
     s = _loops().orc_exact_sum(_p(Kinv), _p(beta), _p(C), _p(x), _p(u), _p(Linv), float(nc2), gp.n, gp.d)
     return mu + gp.meant, (v + vt) - s - mu ** 2
+
+
+# --------------------------------------------------------------------------------------------
+# "next" row f3: Snelson sparse pseudo-input covariance  (reference: Covariance.py:692-1019)
+# theta = (log v, log vt, log w_1..d, pseudo-inputs flattened row-major)
+# --------------------------------------------------------------------------------------------
+
+def spgp_split(theta, d, m):
+    """(theta_gc, x_m)  (Covariance.py:713-714, :738-739)."""
+    theta = np.asarray(theta, dtype=float)
+    return theta[:2 + d], np.reshape(theta[2 + d:], (m, d))
+
+
+def _spgp_lm(theta_gc, xm):
+    return cholesky(gram_ij(xm, xm, theta_gc) + 1e-5 * np.eye(len(xm)), lower=True)
+
+
+def spgp_cov_matrix_ij(xi, xj, theta, m):
+    """Q_ij = K_iM (K_M + 1e-5 I)^-1 K_Mj, no diagonal correction  (Covariance.py:734-757)."""
+    d = np.shape(xi)[1]
+    tg, xm = spgp_split(theta, d, m)
+    Zi = solve_triangular(_spgp_lm(tg, xm), gram_ij(xm, xi, tg), lower=True)
+    Zj = solve_triangular(_spgp_lm(tg, xm), gram_ij(xm, xj, tg), lower=True)
+    return np.dot(Zi.T, Zj)
+
+
+def spgp_lambda(x, theta, m):
+    """diag(K_N - Q_N) + vt  (Covariance.py:829-831)."""
+    d = np.shape(x)[1]
+    tg, _xm = spgp_split(theta, d, m)
+    v, vt, _w = unpack_theta(tg)
+    return v - np.diag(spgp_cov_matrix_ij(x, x, theta, m)) + vt
+
+
+def spgp_cov_matrix(x, theta, m):
+    """Q_N + diag(K_N - Q_N) + vt I  (Covariance.py:814-833)."""
+    Q = spgp_cov_matrix_ij(x, x, theta, m)
+    return Q + np.diag(spgp_lambda(x, theta, m))
+
+
+def spgp_inv_cov_matrix(x, theta, m):
+    """Woodbury: LIinv - LIinv K_NM (B + 1e-5 I)^-1 K_MN LIinv, B = K_M + K_MN LIinv K_NM  (Covariance.py:835-863)."""
+    d = np.shape(x)[1]
+    tg, xm = spgp_split(theta, d, m)
+    li = 1.0 / spgp_lambda(x, theta, m)
+    Knm = gram_ij(x, xm, tg)
+    B = gram_ij(xm, xm, tg) + np.dot(Knm.T, li[:, None] * Knm)
+    LB = cholesky(B + 1e-5 * np.eye(m), lower=True)
+    Y = solve_triangular(LB, Knm.T, lower=True) * li[None, :]
+    return np.diag(li) - np.dot(Y.T, Y)
+
+
+def spgp_nll(x, t, theta, m):
+    """Snelson's O(N M^2) likelihood with jitter 1e-6  (Covariance.py:981-1019)."""
+    x = np.asarray(x, dtype=float)
+    N, d = x.shape
+    tg, xm = spgp_split(theta, d, m)
+    v, vt, _w = unpack_theta(tg)
+    y = np.asarray(t, dtype=float)
+    L = cholesky(gram_ij(xm, xm, tg) + 1e-6 * np.eye(m), lower=True)
+    V = solve_triangular(L, gram_ij(xm, x, tg), lower=True)
+    ep = 1.0 + (v - (V ** 2).sum(0)) / vt
+    V = V / np.sqrt(ep)[None, :]
+    y = y / np.sqrt(ep)
+    Lm = cholesky(vt * np.eye(m) + np.dot(V, V.T), lower=True)
+    bet = solve_triangular(Lm, np.dot(V, y), lower=True)
+    return (np.log(np.diag(Lm)).sum() + (N - m) / 2.0 * np.log(vt) + (np.dot(y, y) - np.dot(bet, bet)) / 2.0 / vt
+            + np.log(ep).sum() / 2.0 + 0.5 * N * np.log(2 * np.pi))
+
+
+def spgp_generic_nll(x, t, theta, m):
+    """Base-class likelihood on the dense SPGP covariance  (Covariance.py:197-216 with :814-833)."""
+    K = spgp_cov_matrix(x, theta, m)
+    t = np.asarray(t, dtype=float)
+    return 0.5 * len(t) * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(K)[1] + 0.5 * np.dot(t, np.linalg.solve(K, t))
+
+
+class OracleSPGP(object):
+    """GaussianProcess(x, t, SPGPCovariance(m), theta): the generic dense formulas on Q and the Woodbury inverse
+    (GaussianProcess.py:19-41, :68-80)."""
+
+    def __init__(self, x, t, theta, m):
+        self.x = np.asarray(x, dtype=float)
+        self.m = m
+        self.meant = np.mean(t)
+        self.t = np.asarray(t, dtype=float) - self.meant
+        self.theta_min = np.asarray(theta, dtype=float)
+        self.Kinv = spgp_inv_cov_matrix(self.x, self.theta_min, m)
+
+    def estimate_many(self, x_stars):
+        xs = np.asarray(x_stars, dtype=float)
+        k = spgp_cov_matrix(xs, self.theta_min, self.m)
+        kv = spgp_cov_matrix_ij(xs, self.x, self.theta_min, self.m)
+        mean = np.dot(kv, np.dot(self.Kinv, self.t))
+        var = k - np.dot(kv, np.dot(self.Kinv, kv.T))
+        return mean + self.meant, np.diag(var)

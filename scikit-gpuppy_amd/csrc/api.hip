@@ -139,7 +139,7 @@ std::map<void *, PoolKey> g_pool_live;
 size_t g_pool_cached_bytes = 0;
 }   // namespace
 
-static int dalloc(double **p, int64_t elems)
+int dalloc(double **p, int64_t elems)
 {
     *p = nullptr;
     if (elems <= 0) elems = 1;
@@ -177,7 +177,7 @@ static int dalloc(double **p, int64_t elems)
 }
 
 // the caller guarantees that no kernel still uses p (every entry point synchronises its stream before freeing)
-static void dfree(void *p)
+void dfree(void *p)
 {
     if (!p) return;
     std::lock_guard<std::mutex> lk(g_pool_mu);

@@ -133,5 +133,10 @@ int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad,
 int launch_set_identity(double *Z, int64_t ld, int64_t n, hipStream_t s);
 int launch_symmetrize_lower(double *A, int64_t ld, int64_t n, hipStream_t s);
 
+// caching device allocator (api.hip)
+int dalloc(double **p, int64_t elems);
+void dfree(void *p);
+
 // propagate.hip
+int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
 int propagate_build_V(gpx_handle *h, const double *u_host);

@@ -262,6 +262,10 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         return GPX_ERR_BAD_ARG;
     }
     if (M == 0 || N == 0) return 0;
+    if (alpha == 0.0) {   // C enters the accumulators as (beta/alpha) C
+        gpx_set_error("launch_gemm_nt: alpha must be non-zero");
+        return GPX_ERR_BAD_ARG;
+    }
     if (lower_only && M != N) {
         gpx_set_error("launch_gemm_nt: lower_only needs a square C");
         return GPX_ERR_BAD_ARG;

@@ -1,0 +1,400 @@
+// spgp.hip -- Snelson sparse pseudo-input GP ("next" row f3; BASELINE config 5: M = 2048 pseudo-inputs, N = 262144).
+//
+// Reference: SPGPCovariance, skgpuppy/Covariance.py:692-1019.  The reference forms N x N matrices (cov_matrix :814-833,
+// the Woodbury inverse :835-863) and predicts through the generic GaussianProcess formulas
+// (GaussianProcess.py:68-80, "TODO Optimize for the SPGP covariance function"); only its likelihood (:981-1019,
+// after Snelson 2006) is O(N M^2).  Here the fit and the predictor stay low rank in HBM:
+//   K_NM (N x M Gram), L_M = chol(K_M + 1e-5 I), Z = K_NM L_M^-T, lambda_n = v + vt - |Z_n|^2,
+//   B~ = K_M + 1e-5 I + K_MN Lambda^-1 K_NM   (the reference's chol(B + 1e-5 I)),  beta = B~^-1 K_MN Lambda^-1 t,
+//   mean* = K_*M beta,   var* = v + vt - |K_*M L_M^-T|^2 + |K_*M L_B^-T|^2.
+// With Q = K_NM (K_M + 1e-5 I)^-1 K_MN, Woodbury gives (Q + Lambda)^-1 = Lambda^-1 - Lambda^-1 K_NM B~^-1 K_MN Lambda^-1
+// exactly, so these are the reference's  kv Kinv t  and  diag(k - kv Kinv kv^T)  without any N x N matrix.
+// All O(N M^2) work runs through the fp64 MFMA GEMM / blocked Cholesky / TRSM of the dense path.
+#include <math.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+struct gpx_spgp {
+    int device = 0;
+    int64_t n = 0, npad = 0, m = 0, mpad = 0, mblk = 0;
+    int d = 0;
+    double v = 0, vt = 0;
+    hipStream_t stream = nullptr;
+    double *xw = nullptr, *xbw = nullptr, *sw = nullptr, *t = nullptr;
+    double *Knm = nullptr;   // [npad, mpad] K_NM, zero padded
+    double *Z = nullptr;     // [npad, mpad] scratch (K_NM L^-T for whichever L was applied last)
+    double *Wt = nullptr;    // [mpad, npad] scratch: a row-scaled transpose of K_NM or Z
+    double *LM = nullptr, *DinvM = nullptr, *diagM = nullptr;   // chol(K_M + 1e-5 I)
+    double *LB = nullptr, *DinvB = nullptr, *diagB = nullptr;   // chol(B + 1e-5 I)
+    double *lam = nullptr;   // [npad] lambda_n
+    double *ilam = nullptr;  // [npad] 1/sqrt(lambda_n), 0 in the padding
+    double *va = nullptr, *vb = nullptr, *vc = nullptr;         // [npad] vector scratch
+    double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad]
+    double *outd = nullptr;  // [8] scalar results
+    int *info = nullptr;
+};
+
+// out[j][i] = in[i][j] * scale[i]   (in: [rows, ldin] -> out: [cols, ldout]; 32x32 LDS tiles)
+__global__ __launch_bounds__(256) void scale_transpose_kernel(const double *__restrict__ in, long ldin, long rows, long cols,
+                                                             const double *__restrict__ scale, double *__restrict__ out, long ldout)
+{
+    __shared__ double tile[32][33];
+    const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long i = r0 + r, j = c0 + tx;
+        tile[r][tx] = (i < rows && j < cols) ? in[i * ldin + j] * scale[i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const long j = c0 + r, i = r0 + tx;
+        if (i < rows && j < cols) out[j * ldout + i] = tile[tx][r];
+    }
+}
+
+// Z[i][:] *= s[i]   (one workgroup per row)
+__global__ __launch_bounds__(256) void scale_rows_inplace_kernel(double *Z, long ld, long cols, const double *__restrict__ sc)
+{
+    const long i = blockIdx.x;
+    const double f = sc[i];
+    for (long j = threadIdx.x; j < cols; j += 256) Z[i * ld + j] *= f;
+}
+
+enum { VEC_INV_SQRT = 0, VEC_SNELSON_EP = 1, VEC_MUL = 2, VEC_SUB = 3, VEC_SQUARE = 4 };
+// small elementwise passes over vectors of length npad (n real entries)
+__global__ __launch_bounds__(256) void spgp_vec_kernel(int mode, long n, long npad, double vt, const double *__restrict__ p,
+                                                      const double *__restrict__ q, double *__restrict__ o1, double *__restrict__ o2)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    const bool real = i < n;
+    switch (mode) {
+    case VEC_INV_SQRT:      // o1 = 1/sqrt(p)
+        o1[i] = real ? 1.0 / sqrt(p[i]) : 0.0;
+        break;
+    case VEC_SNELSON_EP: {  // p = v + vt - sum_m V^2 ;  ep = 1 + (p - vt)/vt ; o1 = 1/sqrt(ep), o2 = log(ep)   (Covariance.py:1002-1003)
+        const double ep = 1.0 + (p[i] - vt) / vt;
+        o1[i] = real ? 1.0 / sqrt(ep) : 0.0;
+        o2[i] = real ? log(ep) : 0.0;
+        break;
+    }
+    case VEC_MUL: o1[i] = real ? p[i] * q[i] : 0.0; break;
+    case VEC_SUB: o1[i] = real ? p[i] - q[i] : 0.0; break;
+    case VEC_SQUARE: o1[i] = real ? p[i] * p[i] : 0.0; break;
+    }
+}
+
+static int vec_op(int mode, int64_t n, int64_t npad, double vt, const double *p, const double *q, double *o1, double *o2, hipStream_t s)
+{
+    hipLaunchKernelGGL(spgp_vec_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, mode, (long)n, (long)npad, vt, p, q, o1, o2);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void sum_kernel(const double *__restrict__ p, long n, double *out)
+{
+    __shared__ double ws[4];
+    double s = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) s += p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// A[i][i] += d[i] (mode 0) or d[i]^2 (mode 1: d = 1/sqrt(lambda) -> 1/lambda)
+__global__ __launch_bounds__(256) void add_diag_kernel(double *A, long ld, long n, const double *__restrict__ dvec, int mode)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[i * ld + i] += mode ? dvec[i] * dvec[i] : dvec[i];
+}
+
+static int spgp_require(gpx_spgp *h)
+{
+    if (!h) { gpx_set_error("null SPGP handle"); return GPX_ERR_BAD_ARG; }
+    GPX_HIP(hipSetDevice(h->device));
+    return 0;
+}
+
+extern "C" void gpx_spgp_free(gpx_spgp *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void *bufs[] = {h->xw, h->xbw, h->sw, h->t, h->Knm, h->Z, h->Wt, h->LM, h->DinvM, h->diagM, h->LB, h->DinvB, h->diagB, h->lam,
+                    h->ilam, h->va, h->vb, h->vc, h->ma, h->mb, h->mzero, h->beta, h->mscr, h->outd};
+    for (void *p : bufs) dfree(p);
+    if (h->info) (void)hipFree(h->info);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// L = chol(K_M + jitter I) with identity padding; LAPACK-style info through *info_h (stream synchronised)
+static int spgp_chol_km(gpx_spgp *h, double jitter, double *L, double *Dinv, double *diag, int *info_h)
+{
+    hipStream_t s = h->stream;
+    GPX_TRY(launch_gram(h->xbw, h->m, h->xbw, h->m, h->d, h->v, jitter, 1, 2, L, h->mpad, h->mpad, h->mpad, s, nullptr));
+    GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
+    GPX_TRY(chol_factor(L, h->mpad, h->mblk, Dinv, diag, h->info, s, nullptr, nullptr, nullptr));
+    GPX_HIP(hipMemcpyAsync(info_h, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+// Z <- K_NM L^-T
+static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv)
+{
+    GPX_HIP(hipMemcpyAsync(h->Z, h->Knm, sizeof(double) * h->npad * h->mpad, hipMemcpyDeviceToDevice, h->stream));
+    return trsm_right_lt(h->Z, h->mpad, h->npad, L, h->mpad, Dinv, 0, h->mblk, h->stream, nullptr);
+}
+
+static int spgp_transpose(gpx_spgp *h, const double *src, const double *row_scale, double *dst)
+{
+    dim3 grid((unsigned)((h->mpad + 31) / 32), (unsigned)((h->npad + 31) / 32));
+    hipLaunchKernelGGL(scale_transpose_kernel, grid, dim3(256), 0, h->stream, src, (long)h->mpad, (long)h->npad, (long)h->mpad, row_scale,
+                       dst, (long)h->npad);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered, const double *theta, const double *xb)
+{
+    const int64_t n = h->n, m = h->m, np = h->npad, mp = h->mpad;
+    const int d = h->d;
+    double sw[GPX_MAX_D];
+    for (int k = 0; k < d; ++k) sw[k] = sqrt(exp(theta[2 + k]));
+    GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    hipStream_t s = h->stream;
+    const int64_t tt = h->mblk * (int64_t)TILE * TILE;
+    GPX_TRY(dalloc(&h->xw, np * d)); GPX_TRY(dalloc(&h->xbw, mp * d)); GPX_TRY(dalloc(&h->sw, d)); GPX_TRY(dalloc(&h->t, np));
+    GPX_TRY(dalloc(&h->Knm, np * mp)); GPX_TRY(dalloc(&h->Z, np * mp)); GPX_TRY(dalloc(&h->Wt, mp * np));
+    GPX_TRY(dalloc(&h->LM, mp * mp)); GPX_TRY(dalloc(&h->DinvM, tt)); GPX_TRY(dalloc(&h->diagM, mp));
+    GPX_TRY(dalloc(&h->LB, mp * mp)); GPX_TRY(dalloc(&h->DinvB, tt)); GPX_TRY(dalloc(&h->diagB, mp));
+    GPX_TRY(dalloc(&h->lam, np)); GPX_TRY(dalloc(&h->ilam, np)); GPX_TRY(dalloc(&h->va, np)); GPX_TRY(dalloc(&h->vb, np)); GPX_TRY(dalloc(&h->vc, np));
+    GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
+    GPX_TRY(dalloc(&h->outd, 8));
+    GPX_HIP(hipMalloc((void **)&h->info, sizeof(int)));
+    // raw inputs are staged through Z / LB (both overwritten below)
+    GPX_HIP(hipMemcpyAsync(h->Z, x, sizeof(double) * n * d, hipMemcpyDefault, s));
+    GPX_HIP(hipMemcpyAsync(h->LB, xb, sizeof(double) * m * d, hipMemcpyDefault, s));
+    GPX_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * np, s));
+    GPX_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
+    GPX_HIP(hipMemsetAsync(h->mzero, 0, sizeof(double) * mp, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    GPX_TRY(launch_scale_rows(h->Z, n, np, d, h->sw, h->xw, s));
+    GPX_TRY(launch_scale_rows(h->LB, m, mp, d, h->sw, h->xbw, s));
+    GPX_HIP(hipStreamSynchronize(s));
+
+    // K_NM and L_M = chol(K_M + 1e-5 I)                                        (Covariance.py:843-846)
+    GPX_TRY(launch_gram(h->xw, n, h->xbw, m, d, h->v, 0.0, 0, 1, h->Knm, mp, np, mp, s, nullptr));
+    int info = 0;
+    GPX_TRY(spgp_chol_km(h, 1e-5, h->LM, h->DinvM, h->diagM, &info));
+    if (info > 0) { gpx_set_error("K_M + 1e-5 I is not positive definite (leading minor %d)", info); return info; }
+    // Z = K_NM L_M^-T ; lambda = diag(K_N - Q_N) + vt = v + vt - |Z_n|^2     (:847-853)
+    GPX_TRY(spgp_solve_into_z(h, h->LM, h->DinvM));
+    GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->lam, s, nullptr));
+    GPX_TRY(vec_op(VEC_INV_SQRT, n, np, 0.0, h->lam, nullptr, h->ilam, nullptr, s));
+    // W^T = (Lambda^-1/2 K_NM)^T ;  B~ = K_M + 1e-5 I + W^T W                   (:856-858)
+    GPX_TRY(spgp_transpose(h, h->Knm, h->ilam, h->Wt));
+    GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 1e-5, 1, 2, h->LB, mp, mp, mp, s, nullptr));
+    GPX_TRY(launch_gemm_nt(h->Wt, np, h->Wt, np, h->LB, mp, mp, mp, np, 1.0, 1.0, 1, s, nullptr));
+    GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
+    GPX_TRY(chol_factor(h->LB, mp, h->mblk, h->DinvB, h->diagB, h->info, s, nullptr, nullptr, nullptr));
+    GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    if (info > 0) { gpx_set_error("B + 1e-5 I is not positive definite (leading minor %d)", info); return info; }
+    // r = K_MN Lambda^-1 t = W^T (Lambda^-1/2 t) ;  beta = B~^-1 r             (commented estimate, :781-784)
+    GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->ilam, h->va, nullptr, s));
+    GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->va, 0.0, h->ma, h->mb, s, nullptr));
+    GPX_TRY(trsv_forward(h->LB, mp, h->DinvB, h->mblk, h->ma, h->mb, h->mscr, s, nullptr));
+    GPX_TRY(trsv_backward(h->LB, mp, h->DinvB, h->mblk, h->mb, h->beta, h->mscr, s, nullptr));
+    GPX_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int gpx_spgp_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, const double *xb,
+                            int64_t m, gpx_spgp **out)
+{
+    if (out) *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        gpx_set_error("no HIP device visible: libgpx has no CPU fallback");
+        return GPX_ERR_NO_DEVICE;
+    }
+    if (!x || !t_centered || !theta || !xb || !out || n < 1 || m < 1 || d < 1 || d > GPX_MAX_D) {
+        gpx_set_error("gpx_spgp_fit: bad arguments (n=%ld m=%ld d=%d)", (long)n, (long)m, d);
+        return GPX_ERR_BAD_ARG;
+    }
+    for (int k = 0; k < d + 2; ++k)
+        if (!std::isfinite(theta[k])) { gpx_set_error("gpx_spgp_fit: theta[%d] is not finite", k); return GPX_ERR_BAD_ARG; }
+    gpx_spgp *h = new (std::nothrow) gpx_spgp();
+    if (!h) { gpx_set_error("out of host memory"); return GPX_ERR_HIP; }
+    (void)hipGetDevice(&h->device);
+    h->n = n; h->m = m; h->d = d;
+    h->npad = round_up(n, TILE); h->mpad = round_up(m, TILE); h->mblk = h->mpad / TILE;
+    h->v = exp(theta[0]); h->vt = exp(theta[1]);
+    const int rc = spgp_fit_body(h, x, t_centered, theta, xb);
+    if (rc) { gpx_spgp_free(h); return rc; }
+    *out = h;
+    return 0;
+}
+
+extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, double *mean_out, double *var_out)
+{
+    GPX_TRY(spgp_require(h));
+    if (ms < 0 || (ms > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_spgp_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (ms == 0) return 0;
+    hipStream_t s = h->stream;
+    const int d = h->d;
+    const int64_t mp = h->mpad;
+    const int64_t chunk = std::min<int64_t>(round_up(ms, TILE), 65536);
+    double *xq = nullptr, *xqw = nullptr, *Ka = nullptr, *Kb = nullptr, *o = nullptr;
+    auto body = [&]() -> int {
+        GPX_TRY(dalloc(&xq, chunk * d)); GPX_TRY(dalloc(&xqw, chunk * d)); GPX_TRY(dalloc(&Ka, chunk * mp)); GPX_TRY(dalloc(&Kb, chunk * mp));
+        GPX_TRY(dalloc(&o, 5 * chunk));
+        double *mean = o, *unused = o + chunk, *va = o + 2 * chunk, *vb = o + 3 * chunk, *var = o + 4 * chunk;
+        for (int64_t q0 = 0; q0 < ms; q0 += chunk) {
+            const int64_t qc = std::min<int64_t>(chunk, ms - q0), qp = round_up(qc, TILE);
+            GPX_HIP(hipMemcpyAsync(xq, xs + q0 * d, sizeof(double) * qc * d, hipMemcpyDefault, s));
+            GPX_TRY(launch_scale_rows(xq, qc, qp, d, h->sw, xqw, s));
+            GPX_TRY(launch_gram(xqw, qc, h->xbw, h->m, d, h->v, 0.0, 0, 1, Ka, mp, qp, mp, s, nullptr));   // K_*M
+            GPX_HIP(hipMemcpyAsync(Kb, Ka, sizeof(double) * qp * mp, hipMemcpyDeviceToDevice, s));
+            GPX_TRY(launch_predict_reduce(Ka, mp, qc, mp, h->beta, 0.0, mean, unused, s, nullptr));       // K_*M beta
+            GPX_TRY(trsm_right_lt(Ka, mp, qp, h->LM, mp, h->DinvM, 0, h->mblk, s, nullptr));
+            GPX_TRY(trsm_right_lt(Kb, mp, qp, h->LB, mp, h->DinvB, 0, h->mblk, s, nullptr));
+            GPX_TRY(launch_predict_reduce(Ka, mp, qc, mp, h->mzero, h->v + h->vt, unused, va, s, nullptr));   // v + vt - |K_*M L_M^-T|^2
+            GPX_TRY(launch_predict_reduce(Kb, mp, qc, mp, h->mzero, 0.0, unused, vb, s, nullptr));            //        - |K_*M L_B^-T|^2
+            GPX_TRY(vec_op(VEC_SUB, qc, qc, 0.0, va, vb, var, nullptr, s));
+            GPX_HIP(hipMemcpyAsync(mean_out + q0, mean, sizeof(double) * qc, hipMemcpyDefault, s));
+            GPX_HIP(hipMemcpyAsync(var_out + q0, var, sizeof(double) * qc, hipMemcpyDefault, s));
+            GPX_HIP(hipStreamSynchronize(s));
+        }
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
+    dfree(xq); dfree(xqw); dfree(Ka); dfree(Kb); dfree(o);
+    return rc;
+}
+
+// Snelson's O(N M^2) negative log likelihood (Covariance.py:981-1019); jitter delta = 1e-6 on K_M as there (:995-998)
+extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
+{
+    GPX_TRY(spgp_require(h));
+    if (!nll_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    const int64_t np = h->npad, mp = h->mpad, n = h->n, m = h->m;
+    const int64_t tt = h->mblk * (int64_t)TILE * TILE;
+    double *L = nullptr, *Dinv = nullptr, *diag = nullptr, *A = nullptr, *DinvA = nullptr, *diagA = nullptr;
+    int info = 0;
+    double o[4] = {0, 0, 0, 0};
+    auto body = [&]() -> int {
+        GPX_TRY(dalloc(&L, mp * mp)); GPX_TRY(dalloc(&Dinv, tt)); GPX_TRY(dalloc(&diag, mp));
+        GPX_TRY(dalloc(&A, mp * mp)); GPX_TRY(dalloc(&DinvA, tt)); GPX_TRY(dalloc(&diagA, mp));
+        GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
+        if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
+        GPX_TRY(spgp_solve_into_z(h, L, Dinv));                                                     // Z = V^T,  V = L^-1 K_MN
+        GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->vb, s, nullptr));   // vb = v + vt - sum V^2
+        GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, h->vb, nullptr, h->va, h->vc, s));             // va = 1/sqrt(ep), vc = log ep
+        GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->va, h->vb, nullptr, s));                       // vb = y / sqrt(ep)
+        GPX_TRY(spgp_transpose(h, h->Z, h->va, h->Wt));                                             // Wt = V / sqrt(ep)  [M, N]
+        GPX_TRY(launch_set_identity(A, mp, mp, s));
+        GPX_TRY(launch_gemm_nt(h->Wt, np, h->Wt, np, A, mp, mp, mp, np, 1.0, h->vt, 1, s, nullptr));   // A = vt I + V V^T
+        GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
+        GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));  // Lm
+        GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V y
+        GPX_TRY(trsv_forward(A, mp, DinvA, h->mblk, h->ma, h->mb, h->mscr, s, nullptr));            // bet = Lm^-1 V y
+        std::vector<std::pair<const double *, const double *>> pr;
+        pr.push_back({h->vb, h->vb});
+        GPX_TRY(launch_dot_pairs(pr, np, h->outd, s));                                              // y^T y
+        pr[0] = {h->mb, h->mb};
+        GPX_TRY(launch_dot_pairs(pr, m, h->outd + 1, s));                                           // bet^T bet over the real M
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, (const double *)h->vc, (long)np, h->outd + 2);   // sum log ep
+        GPX_TRY(launch_logdet(diagA, m, h->outd + 3, s));                                           // 2 sum log diag(Lm)
+        GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipMemcpyAsync(o, h->outd, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        if (info > 0) { gpx_set_error("vt I + V V^T is not positive definite (leading minor %d)", info); return info; }
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
+    dfree(L); dfree(Dinv); dfree(diag); dfree(A); dfree(DinvA); dfree(diagA);
+    if (rc) return rc;
+    // fw = sum log diag(Lm) + (N-M)/2 log vt + (y^T y - bet^T bet)/(2 vt) + sum log(ep)/2 + N/2 log 2 pi   (:1017)
+    *nll_out = 0.5 * o[3] + 0.5 * (double)(n - m) * log(h->vt) + (o[0] - o[1]) / (2.0 * h->vt) + 0.5 * o[2] + 0.5 * (double)n * log(2.0 * M_PI);
+    return 0;
+}
+
+// Dense N x N views of the fitted model, for the reference's accessors (small N only):
+//   which = 0: cov_matrix(x)      = Q_N + diag(K_N - Q_N) + vt I                        (Covariance.py:814-833)
+//   which = 1: inv_cov_matrix(x)  = Lambda^-1 - Lambda^-1 K_NM B~^-1 K_MN Lambda^-1     (:835-863)
+extern "C" int gpx_spgp_dense(gpx_spgp *h, int which, double *out)
+{
+    GPX_TRY(spgp_require(h));
+    if (!out || which < 0 || which > 1) { gpx_set_error("gpx_spgp_dense: bad arguments"); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    const int64_t np = h->npad, mp = h->mpad, n = h->n;
+    double *C = nullptr;
+    auto body = [&]() -> int {
+        GPX_TRY(dalloc(&C, np * np));
+        const dim3 dg((unsigned)((n + 255) / 256));
+        if (which == 0) {
+            GPX_TRY(spgp_solve_into_z(h, h->LM, h->DinvM));
+            GPX_TRY(launch_gemm_nt(h->Z, mp, h->Z, mp, C, np, np, np, mp, 1.0, 0.0, 0, s, nullptr));      // Q_N = Z Z^T
+            hipLaunchKernelGGL(add_diag_kernel, dg, dim3(256), 0, s, C, (long)np, (long)n, (const double *)h->lam, 0);
+        } else {
+            GPX_TRY(spgp_solve_into_z(h, h->LB, h->DinvB));                                            // K_NM L_B^-T
+            GPX_TRY(vec_op(VEC_SQUARE, n, np, 0.0, h->ilam, nullptr, h->va, nullptr, s));               // 1/lambda
+            hipLaunchKernelGGL(scale_rows_inplace_kernel, dim3((unsigned)np), dim3(256), 0, s, h->Z, (long)mp, (long)mp, (const double *)h->va);
+            GPX_TRY(launch_gemm_nt(h->Z, mp, h->Z, mp, C, np, np, np, mp, -1.0, 0.0, 0, s, nullptr));
+            hipLaunchKernelGGL(add_diag_kernel, dg, dim3(256), 0, s, C, (long)np, (long)n, (const double *)h->ilam, 1);
+        }
+        GPX_HIP(hipGetLastError());
+        GPX_HIP(hipMemcpy2DAsync(out, sizeof(double) * n, C, sizeof(double) * np, sizeof(double) * n, n, hipMemcpyDefault, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
+    dfree(C);
+    return rc;
+}
+
+// cov_matrix_ij(xi, xj) = Q_ij = K_iM (K_M + 1e-5 I)^-1 K_Mj   (Covariance.py:734-757), [n1, n2] row-major
+extern "C" int gpx_spgp_cross(gpx_spgp *h, const double *xi, int64_t n1, const double *xj, int64_t n2, double *out)
+{
+    GPX_TRY(spgp_require(h));
+    if (n1 < 0 || n2 < 0 || ((n1 > 0 && n2 > 0) && (!xi || !xj || !out))) { gpx_set_error("gpx_spgp_cross: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (n1 == 0 || n2 == 0) return 0;
+    hipStream_t s = h->stream;
+    const int d = h->d;
+    const int64_t mp = h->mpad, p1 = round_up(n1, TILE), p2 = round_up(n2, TILE);
+    double *raw = nullptr, *xw = nullptr, *Z1 = nullptr, *Z2 = nullptr, *C = nullptr;
+    auto side = [&](const double *x, int64_t n, int64_t p, double *Zout) -> int {
+        GPX_HIP(hipMemcpyAsync(raw, x, sizeof(double) * n * d, hipMemcpyDefault, s));
+        GPX_TRY(launch_scale_rows(raw, n, p, d, h->sw, xw, s));
+        GPX_TRY(launch_gram(xw, n, h->xbw, h->m, d, h->v, 0.0, 0, 1, Zout, mp, p, mp, s, nullptr));
+        return trsm_right_lt(Zout, mp, p, h->LM, mp, h->DinvM, 0, h->mblk, s, nullptr);
+    };
+    auto body = [&]() -> int {
+        const int64_t pm = std::max(p1, p2);
+        GPX_TRY(dalloc(&raw, pm * d)); GPX_TRY(dalloc(&xw, pm * d)); GPX_TRY(dalloc(&Z1, p1 * mp)); GPX_TRY(dalloc(&Z2, p2 * mp));
+        GPX_TRY(dalloc(&C, p1 * p2));
+        GPX_TRY(side(xi, n1, p1, Z1));
+        GPX_TRY(side(xj, n2, p2, Z2));
+        GPX_TRY(launch_gemm_nt(Z1, mp, Z2, mp, C, p2, p1, p2, mp, 1.0, 0.0, 0, s, nullptr));
+        GPX_HIP(hipMemcpy2DAsync(out, sizeof(double) * n2, C, sizeof(double) * p2, sizeof(double) * n2, n1, hipMemcpyDefault, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
+    dfree(raw); dfree(xw); dfree(Z1); dfree(Z2); dfree(C);
+    return rc;
+}

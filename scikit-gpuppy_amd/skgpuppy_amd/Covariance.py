@@ -211,3 +211,145 @@ class GaussianCovariance(Covariance):
         diff = np.asarray(xi, dtype=float) - np.asarray(u, dtype=float)
         e = v * np.exp(-0.5 * np.dot(diff, w * diff))
         return np.atleast_2d(-diff * w * e).T
+
+
+class _SPGPDeviceModel(object):
+    """Owner of one gpx_spgp handle: K_NM, chol(K_M + 1e-5 I), Lambda and chol(B + 1e-5 I) resident in HBM."""
+
+    def __init__(self, x, t_centered, theta_gc, xb):
+        self.n, self.d = x.shape
+        self.m = xb.shape[0]
+        self._h = ctypes.c_void_p()
+        st = _gpx.lib.gpx_spgp_fit(_gpx.ptr(x), _gpx.ptr(t_centered), self.n, self.d, _gpx.ptr(theta_gc), _gpx.ptr(xb),
+                                   self.m, ctypes.byref(self._h))
+        _gpx.check(st, "gpx_spgp_fit")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("device model already released")
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _gpx.lib.gpx_spgp_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    __del__ = close
+
+    def predict(self, xs):
+        k = xs.shape[0]
+        mean = np.empty(k)
+        var = np.empty(k)
+        _gpx.check(_gpx.lib.gpx_spgp_predict(self.handle, _gpx.ptr(xs), k, _gpx.ptr(mean), _gpx.ptr(var)), "gpx_spgp_predict")
+        return mean, var
+
+    def nll(self):
+        out = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_spgp_nll(self.handle, ctypes.byref(out)), "gpx_spgp_nll")
+        return out.value
+
+    def dense(self, which):
+        out = np.empty((self.n, self.n))
+        _gpx.check(_gpx.lib.gpx_spgp_dense(self.handle, which, _gpx.ptr(out)), "gpx_spgp_dense")
+        return out
+
+    def kinv(self):
+        return self.dense(1)
+
+    def cross(self, xi, xj):
+        out = np.empty((xi.shape[0], xj.shape[0]))
+        if out.size:
+            _gpx.check(_gpx.lib.gpx_spgp_cross(self.handle, _gpx.ptr(xi), xi.shape[0], _gpx.ptr(xj), xj.shape[0], _gpx.ptr(out)),
+                       "gpx_spgp_cross")
+        return out
+
+
+class SPGPCovariance(Covariance):
+    """Snelson's sparse pseudo-input covariance ("next" row f3; skgpuppy/Covariance.py:692-1019).
+
+    theta = (log v, log vt, log w_1..w_d, the m pseudo-inputs flattened row-major).  Like the reference's it offers no
+    Jacobian/Hessian (no uncertainty propagation).  Fit, prediction and Snelson's likelihood are O(N m^2) on the GPU;
+    cov_matrix / inv_cov_matrix materialise the reference's N x N matrices for small N only."""
+
+    def __init__(self, m):
+        self.m = m
+        self.cov = GaussianCovariance()
+
+    def _split(self, theta, d):
+        th = _gpx.f64(theta)
+        if th.ndim != 1 or th.shape[0] != 2 + d + self.m * d:
+            raise ValueError("theta must have 2 + d + m*d = %d entries, got shape %r" % (2 + d + self.m * d, th.shape))
+        return np.ascontiguousarray(th[:2 + d]), np.ascontiguousarray(np.reshape(th[2 + d:], (self.m, d)))
+
+    def _model(self, x, t, theta):
+        xa = _gpx.f64(x)
+        if xa.ndim != 2:
+            raise ValueError("x must be an (n, d) array")
+        tg, xb = self._split(theta, xa.shape[1])
+        ta = np.zeros(xa.shape[0]) if t is None else _gpx.f64(t)
+        return _SPGPDeviceModel(xa, ta, tg, xb)
+
+    def __call__(self, xi, xj, theta):
+        # (Covariance.py:708-732): the full kernel on the diagonal, the low-rank one elsewhere
+        xi = np.asarray(xi)
+        xj = np.asarray(xj)
+        d = np.shape(xi)[0]
+        if (xi == xj).all():
+            return self.cov(xi, xj, theta[0:2 + d])
+        return self.cov_matrix_ij(np.atleast_2d(xi), np.atleast_2d(xj), theta)[0, 0]
+
+    def get_theta(self, x, t):
+        # (Covariance.py:734-741): GaussianCovariance start + m training rows drawn at random as pseudo-inputs
+        n, d = np.shape(x)
+        theta = np.ones(2 + d + self.m * d)
+        theta[0:2 + d] = self.cov.get_theta(x, t)
+        theta[2 + d:] = np.reshape(np.asarray(x)[np.random.randint(n, size=self.m), :], self.m * d)
+        return theta
+
+    def cov_matrix_ij(self, xi, xj, theta):
+        """Q_ij = K_iM (K_M + 1e-5 I)^-1 K_Mj (Covariance.py:743-763)."""
+        a = _gpx.f64(xi)
+        b = _gpx.f64(xj)
+        model = self._model(a, None, theta)
+        try:
+            return model.cross(a, b)
+        finally:
+            model.close()
+
+    def cov_matrix(self, x, theta):
+        """Q_N + diag(K_N - Q_N) + vt I (Covariance.py:814-833)."""
+        model = self._model(x, None, theta)
+        try:
+            return model.dense(0)
+        finally:
+            model.close()
+
+    def inv_cov_matrix(self, x, theta, cov_matrix=None):
+        """the Woodbury inverse (Covariance.py:835-863); `cov_matrix` is ignored as in the reference."""
+        model = self._model(x, None, theta)
+        try:
+            return model.dense(1)
+        finally:
+            model.close()
+
+    def _negativeloglikelihood(self, x, t, theta):
+        """Snelson's O(N m^2) likelihood (Covariance.py:981-1019); raises LinAlgError like the reference's Cholesky."""
+        model = self._model(x, t, theta)
+        try:
+            return model.nll()
+        finally:
+            model.close()
+
+    def _d_nll_d_theta(self, x, t, theta):
+        """central differences of the GPU likelihood.  The reference's analytic gradient (Covariance.py:906-979) builds
+        2 + d + m d dense N x N derivative matrices and is itself only checked against central differences
+        (skgpuppy/tests/tests.py:538-565)."""
+        theta = np.asarray(theta, dtype=float)
+        g = np.empty(len(theta))
+        delta = 1e-5
+        for j in range(len(theta)):
+            e = np.zeros(len(theta))
+            e[j] = delta
+            g[j] = (self._negativeloglikelihood(x, t, theta + e) - self._negativeloglikelihood(x, t, theta - e)) / (2 * delta)
+        return g

@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _gpx
-from .Covariance import GaussianCovariance
+from .Covariance import GaussianCovariance, SPGPCovariance
 
 
 class _DeviceModel(object):
@@ -89,8 +89,12 @@ class GaussianProcess(object):
 
     # ---- device model management -----------------------------------------------------------
     def _fit(self):
+        if isinstance(self.cov, SPGPCovariance):
+            # low-rank fit: no N x N matrix (the reference's own "TODO Optimize for the SPGP covariance function")
+            self._model = self.cov._model(self.x, self.t, self.theta_min)
+            return
         if not isinstance(self.cov, GaussianCovariance):
-            raise TypeError("only GaussianCovariance is on the accelerated path")
+            raise TypeError("only GaussianCovariance and SPGPCovariance are on the accelerated path")
         self._model = _DeviceModel(_gpx.f64(self.x), _gpx.f64(self.t), _gpx.f64(self.theta_min))
 
     def _dev(self):
@@ -147,6 +151,8 @@ class GaussianProcess(object):
 
     def _get_beta(self):
         # beta = K^-1 t (GaussianProcess.py:114-119)
+        if isinstance(self.cov, SPGPCovariance):
+            return np.dot(self.Kinv, self.t)
         return self._dev().alpha()
 
     def _get_W_inv(self):

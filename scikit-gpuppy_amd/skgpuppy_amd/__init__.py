@@ -5,7 +5,7 @@ and skgpuppy.UncertaintyPropagation; the arithmetic runs in hand-written HIP ker
 behind a ctypes C-ABI (include/gpx.h).  Importing this package without the built library fails.
 """
 from . import _gpx  # noqa: F401  (fails loudly when libgpx.so is missing)
-from .Covariance import Covariance, GaussianCovariance, tracedot  # noqa: F401
+from .Covariance import Covariance, GaussianCovariance, SPGPCovariance, tracedot  # noqa: F401
 from .GaussianProcess import GaussianProcess  # noqa: F401
 from .UncertaintyPropagation import (  # noqa: F401
     UncertaintyPropagationApprox,
@@ -20,7 +20,7 @@ from .InverseUncertaintyPropagation import (  # noqa: F401,E402
 )
 
 __all__ = [
-    "Covariance", "GaussianCovariance", "GaussianProcess", "UncertaintyPropagationGA",
+    "Covariance", "GaussianCovariance", "SPGPCovariance", "GaussianProcess", "UncertaintyPropagationGA",
     "UncertaintyPropagationApprox", "UncertaintyPropagationExact", "tracedot",
     "InverseUncertaintyPropagation", "InverseUncertaintyPropagationApprox", "InverseUncertaintyPropagationNumerical",
 ]

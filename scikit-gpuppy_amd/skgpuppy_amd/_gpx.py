@@ -56,6 +56,12 @@ SIGNATURES = {
     "gpx_exact_mean": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl)]),
     "gpx_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
     "gpx_nll_grad": (_int, [_hp, _dp]),
+    "gpx_spgp_fit": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _i64, ctypes.POINTER(_hp)]),
+    "gpx_spgp_free": (None, [_hp]),
+    "gpx_spgp_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
+    "gpx_spgp_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_spgp_dense": (_int, [_hp, _int, _dp]),
+    "gpx_spgp_cross": (_int, [_hp, _dp, _i64, _dp, _i64, _dp]),
     "gpx_profile_enable": (_int, [_hp, _int]),
     "gpx_profile_reset": (_int, [_hp]),
     "gpx_profile_read": (_int, [_hp, _int, ctypes.POINTER(_i64), ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),

@@ -495,3 +495,113 @@ def test_kinv_identity_at_scale():
     E[np.arange(64), rows] = 1.0
     assert np.abs(P - E).max() < 1e-8
     np.testing.assert_array_equal(Kinv, Kinv.T)
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f3: SPGP low-rank path vs the reference's golden vectors and the oracle
+# ------------------------------------------------------------------------------------------------
+def _spgp_case(name):
+    g = load_golden("spgp")
+    pre = name + "__"
+    return {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("name", ["grid_m10", "n300_d3_m37", "n700_d4_m150"])
+def test_spgp_golden(name):
+    g = _spgp_case(name)
+    x, t, th, m, xs = g["x"], g["t_raw"], g["theta"], int(g["m"]), g["xs"]
+    cov = sk.SPGPCovariance(m)
+    v = np.exp(th[0])
+    if "cov" in g:
+        np.testing.assert_allclose(cov.cov_matrix(x, th), g["cov"], rtol=0, atol=1e-10 * v)
+        # the inverse amplifies by 1/vt; the reference's own bar is sum|diff| <= 1e-5 (tests.py:529)
+        inv = cov.inv_cov_matrix(x, th)
+        np.testing.assert_allclose(inv, g["inv"], rtol=0, atol=1e-7 * np.abs(g["inv"]).max())
+        assert np.abs(inv - np.linalg.inv(g["cov"])).sum() <= 1e-5 * max(1.0, np.abs(g["inv"]).sum())
+    np.testing.assert_allclose(cov.cov_matrix_ij(xs[:16], x, th), g["cross"], rtol=0, atol=1e-10 * v)
+    assert cov(x[0], x[1], th) == pytest.approx(float(g["scalar_01"]), abs=1e-10 * v)
+    assert cov(x[0], x[0], th) == pytest.approx(float(g["scalar_00"]), abs=1e-12)
+    tc = t - t.mean()
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(float(g["nll_snelson"]), rel=1e-8, abs=1e-6)
+    gp = sk.GaussianProcess(x, t, cov, th.copy())
+    mu, var = gp.estimate_many(xs)
+    np.testing.assert_allclose(mu, g["pred_mean"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(var, g["pred_var"], rtol=0, atol=1e-6 * v)
+    m0, v0 = gp.estimate(xs[0])
+    assert (m0, v0) == pytest.approx(tuple(g["est0"]), abs=5e-6)
+    if "inv" in g:
+        np.testing.assert_allclose(gp.Kinv, g["inv"], rtol=0, atol=1e-7 * np.abs(g["inv"]).max())
+    gp2 = pickle.loads(pickle.dumps(gp))
+    np.testing.assert_allclose(gp2.estimate_many(xs[:5])[0], mu[:5], rtol=0, atol=1e-12)
+
+
+def test_spgp_vs_oracle_ragged_and_large_m():
+    """seeded inputs the reference never saw: N, m not tile multiples, m spanning three 128-blocks."""
+    rng = np.random.RandomState(99)
+    N, d, m = 1500, 5, 300
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (77, d))
+    th_gc = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    xb = rng.uniform(0, 10, (m, d))
+    th = np.concatenate([th_gc, xb.ravel()])
+    cov = sk.SPGPCovariance(m)
+    gp = sk.GaussianProcess(x, t, cov, th.copy())
+    ogp = orc.OracleSPGP(x, t, th, m)
+    mu, var = gp.estimate_many(xs)
+    omu, ovar = ogp.estimate_many(xs)
+    np.testing.assert_allclose(mu, omu, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(var, ovar, rtol=0, atol=2e-6)
+    tc = t - t.mean()
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(orc.spgp_nll(x, tc, th, m), rel=1e-7)
+    # Snelson's O(N m^2) likelihood agrees with the dense one as in the reference's test (tests.py:803)
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(orc.spgp_generic_nll(x, tc, th, m), abs=2e-1 * max(1.0, m / 10.0))
+
+
+def test_spgp_gradient_and_bad_arguments():
+    g = _spgp_case("grid_m10")
+    x, t, th, m = g["x"], g["t_raw"], g["theta"], int(g["m"])
+    cov = sk.SPGPCovariance(m)
+    tc = t - t.mean()
+    gr = cov._d_nll_d_theta(x, tc, th)
+    assert gr.shape == th.shape and np.all(np.isfinite(gr))
+    # directional derivative agrees with a coarser difference quotient of the oracle
+    e = np.zeros(len(th)); e[0] = 1e-4
+    fd = (orc.spgp_nll(x, tc, th + e, m) - orc.spgp_nll(x, tc, th - e, m)) / 2e-4
+    assert gr[0] == pytest.approx(fd, rel=1e-3, abs=1e-3)
+    with pytest.raises(ValueError):
+        cov.cov_matrix(x, th[:-1])
+    start = cov.get_theta(x, tc)
+    assert start.shape == th.shape
+    assert np.isfinite(cov._negativeloglikelihood(x, tc, start))
+
+
+def test_spgp_full_size_properties():
+    """BASELINE config 5 shape (d = 8, m = 2048) at a reduced N: with the pseudo-inputs equal to a subset of the
+    training inputs the SPGP predictor at those inputs reproduces the dense GP's there up to the jitter; variance stays
+    within [0, v + vt]."""
+    rng = np.random.RandomState(5)
+    N, d, m = 8192, 8, 2048
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    th_gc = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    xb = x[:m].copy()
+    th = np.concatenate([th_gc, xb.ravel()])
+    gp = sk.GaussianProcess(x, t, sk.SPGPCovariance(m), th)
+    xs = rng.uniform(0, 10, (4096, d))
+    mu, var = gp.estimate_many(xs)
+    assert np.all(np.isfinite(mu)) and np.all(var > 0) and np.all(var <= 2.01 * (1 + 1e-9))
+    # two query batches == one batch (chunking / padding independence)
+    mu2, var2 = gp.estimate_many(xs[:1000])
+    np.testing.assert_allclose(mu2, mu[:1000], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(var2, var[:1000], rtol=0, atol=1e-10)
+    # with m = N (all inputs are pseudo-inputs) Q_N = K_N (K_N + 1e-5 I)^-1 K_N ~ K_N: the SPGP posterior collapses onto the dense one
+    Ns = 1024
+    xs_s = xs[:64]
+    th_full = np.concatenate([th_gc, x[:Ns].ravel()])
+    sp = sk.GaussianProcess(x[:Ns], t[:Ns], sk.SPGPCovariance(Ns), th_full)
+    de = sk.GaussianProcess(x[:Ns], t[:Ns], sk.GaussianCovariance(), th_gc)
+    ms, vs = sp.estimate_many(xs_s)
+    md, vd = de.estimate_many(xs_s)
+    np.testing.assert_allclose(ms, md, rtol=0, atol=5e-3)
+    np.testing.assert_allclose(vs, vd, rtol=0, atol=5e-3)

@@ -146,3 +146,41 @@ def test_theta_start():
     g = load_golden("kat1_grid")
     t = g["ml_t_raw"] - g["ml_t_raw"].mean()
     np.testing.assert_allclose(orc.theta_start(g["x"], t), g["ml_theta_start"], rtol=1e-14)
+
+
+# ------------------------------------------------------------------------------------------------
+# "next" row f3: SPGP restatement vs the reference (tests/golden/spgp.npz, tools/gen_golden.py --spgp)
+# ------------------------------------------------------------------------------------------------
+SPGP_CASES = ["grid_m10", "n300_d3_m37", "n700_d4_m150"]
+
+
+def spgp_case(name):
+    g = load_golden("spgp")
+    pre = name + "__"
+    return {k[len(pre):]: v for k, v in g.items() if k.startswith(pre)}
+
+
+@pytest.mark.parametrize("name", SPGP_CASES)
+def test_spgp_oracle_matches_reference(name):
+    g = spgp_case(name)
+    x, t, th, m, xs = g["x"], g["t_raw"], g["theta"], int(g["m"]), g["xs"]
+    if "cov" in g:
+        np.testing.assert_allclose(orc.spgp_cov_matrix(x, th, m), g["cov"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(orc.spgp_inv_cov_matrix(x, th, m), g["inv"], rtol=0, atol=1e-9 * np.abs(g["inv"]).max())
+        # the reference's own check (tests.py:521-530): Woodbury inverse == inv(cov_matrix)
+        assert np.abs(np.linalg.inv(g["cov"]) - g["inv"]).sum() <= 1e-5 * max(1.0, np.abs(g["inv"]).sum())
+    np.testing.assert_allclose(orc.spgp_cov_matrix_ij(xs[:16], x, th, m), g["cross"], rtol=0, atol=1e-12)
+    tc = t - t.mean()
+    assert orc.spgp_nll(x, tc, th, m) == pytest.approx(float(g["nll_snelson"]), rel=1e-9)
+    assert orc.spgp_generic_nll(x, tc, th, m) == pytest.approx(float(g["nll_generic"]), rel=1e-6)
+    gp = orc.OracleSPGP(x, t, th, m)
+    mu, var = gp.estimate_many(xs)
+    np.testing.assert_allclose(mu, g["pred_mean"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(var, g["pred_var"], rtol=0, atol=2e-7)
+
+
+def test_spgp_reference_nll_agreement():
+    """the reference's test_spgp_nll (tests.py:768-804): Snelson's likelihood within 2e-1 of the dense one."""
+    for name in SPGP_CASES[:2]:
+        g = spgp_case(name)
+        assert abs(float(g["nll_snelson"]) - float(g["nll_generic"])) < 2e-1

@@ -147,7 +147,60 @@ def gp_case(GC, GP, UP, x, t, theta, xs, us, Sigmas, v_out=0.02, keep_kinv=True,
     return o
 
 
+def spgp_cases():
+    """"next" row f3: SPGPCovariance at fixed theta (cf. skgpuppy/tests/tests.py:506-530, :768-804)."""
+    _install_shims()
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from skgpuppy.Covariance import SPGPCovariance, Covariance
+    from skgpuppy.GaussianProcess import GaussianProcess as GP
+    out = {}
+
+    def one(name, x, t, theta_gc, xm, xs, keep_dense=True):
+        m, d = xm.shape
+        cov = SPGPCovariance(m)
+        theta = np.concatenate([theta_gc, xm.ravel()])
+        c = {"x": x, "t_raw": t, "theta": theta, "m": np.int64(m), "xs": xs}
+        if keep_dense:
+            c["cov"] = cov.cov_matrix(x, theta)
+            c["inv"] = cov.inv_cov_matrix(x, theta)
+        c["cross"] = cov.cov_matrix_ij(xs[:16], x, theta)
+        tc = t - np.mean(t)
+        c["nll_snelson"] = np.float64(cov._negativeloglikelihood(x, tc, theta))
+        c["nll_generic"] = np.float64(Covariance._negativeloglikelihood(cov, x, tc, theta))
+        gp = GP(x, t, cov, theta.copy())
+        c["pred_mean"], c["pred_var"] = gp.estimate_many(xs)
+        c["est0"] = np.array(gp.estimate(xs[0]))
+        c["scalar_01"] = np.float64(cov(x[0], x[1], theta))
+        c["scalar_00"] = np.float64(cov(x[0], x[0], theta))
+        for k, v in c.items():
+            out[name + "__" + k] = v
+
+    rng = np.random.RandomState(4242)
+    a, b = np.meshgrid(np.arange(10.0), np.arange(10.0), indexing="ij")
+    xg = np.stack([a.ravel(), b.ravel()], 1)
+    tg = np.sin(0.3 * (xg[:, 0] + xg[:, 1])) + 0.1 * rng.randn(100)
+    thg = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
+    xm = xg[rng.choice(100, 10, replace=False)] + 0.25 * rng.randn(10, 2)
+    xs = rng.uniform(0, 9, (23, 2))
+    one("grid_m10", xg, tg, thg, xm, xs)
+
+    x, t, xs, th = synth(300, 3, 41, seed_offset=5)
+    xm = x[rng.choice(300, 37, replace=False)] + 0.1 * rng.randn(37, 3)
+    one("n300_d3_m37", x, t, np.array([0.4, -3.5, -1.2, -0.7, -1.9]), xm, xs)
+
+    x, t, xs, th = synth(700, 4, 150, seed_offset=6)
+    xm = rng.uniform(0, 10, (150, 4))
+    one("n700_d4_m150", x, t, th, xm, xs, keep_dense=False)
+    return out
+
+
 def main():
+    if "--spgp" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        np.savez_compressed(os.path.join(OUT, "spgp.npz"), **spgp_cases())
+        print("spgp.npz")
+        return
     GC, GP, UP = _import_reference()
     os.makedirs(OUT, exist_ok=True)
 
