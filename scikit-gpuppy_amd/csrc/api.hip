@@ -323,6 +323,8 @@ extern "C" void gpx_free(gpx_handle *h)
     if (h->info_dev) (void)hipFree(h->info_dev);
     if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); (void)hipStreamDestroy(h->s_pan); }
     if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
+    if (h->leaf.stream) { (void)hipStreamSynchronize(h->leaf.stream); (void)hipStreamDestroy(h->leaf.stream); }
+    if (h->leaf.flags) (void)hipFree(h->leaf.flags);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -332,7 +334,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, &h->leaf));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -390,6 +392,15 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
+            // persistent leaf worker of the look-ahead factorisation: its own high-priority stream + hand-off words
+            static const int wprio = getenv("GPX_LEAF_WORKER_PRIO") ? atoi(getenv("GPX_LEAF_WORKER_PRIO")) : 0;   // 0 = lowest, 1 = highest
+            if (h->s_pan && hipStreamCreateWithPriority(&h->leaf.stream, hipStreamNonBlocking, wprio ? greatest : least) == hipSuccess) {
+                if (hipMalloc((void **)&h->leaf.flags, 4 * sizeof(unsigned long long)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    h->leaf.flags = nullptr;
+                }
+            } else
+                h->leaf.stream = nullptr;
         }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };

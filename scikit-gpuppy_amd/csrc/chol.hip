@@ -13,6 +13,8 @@
 //   trtri128 : inverts the 128x128 factor by recursive doubling over 16x16 blocks on MFMA, so that
 //              every triangular solve against a diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -122,11 +124,11 @@ __global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, doubl
 constexpr int XB = 16 * 17;                                  // doubles per packed block
 __device__ __forceinline__ int xblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * XB; }
 
+__device__ __forceinline__ void trtri128_levels(const double *L, long ld, double *dinv, double *X);
+
 __device__ __forceinline__ void trtri128_body(const double *L, long ld, double *dinv, double *X)
 {
     const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const int fr = lane & 15, fq = lane >> 4;
 
     // stage L's eight diagonal 16x16 blocks (zeros above the diagonal)
     for (int e = t; e < 8 * 256; e += 256) {
@@ -156,6 +158,15 @@ __device__ __forceinline__ void trtri128_body(const double *L, long ld, double *
         for (int i = 0; i < 16; ++i) Xb[i * 17 + c] = xcol[i];   // zero for i < c
     }
     __syncthreads();
+    trtri128_levels(L, ld, dinv, X);
+}
+
+// levels 1..3 of the inverse; on entry X's eight diagonal blocks hold inv(L_bb) (zeros above the diagonal)
+__device__ __forceinline__ void trtri128_levels(const double *L, long ld, double *dinv, double *X)
+{
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int fr = lane & 15, fq = lane >> 4;
 
     // levels s = 1, 2, 4 (block size in 16-units): pairs p of [X11 (s blocks), X22 (s blocks)]
     for (int s = 1; s <= 4; s <<= 1) {
@@ -253,11 +264,361 @@ __global__ __launch_bounds__(256) void potrf_trtri128_kernel(double *A, long ld,
     trtri128_body(A, ld, dinv, X);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Blocked leaf: the same factor + inverse with all O(128^3) work on MFMA.  The register kernel above spends
+// 128 pivots x ~45 dependent fp64 VALU FMAs per wave; when the leaf shares its SIMDs with a bulk GEMM workgroup
+// (it always does under the look-ahead schedule) those VALU instructions queue behind the GEMM's fp64 MFMAs and
+// the leaf runs 2-7x slower.  Here the block lives in LDS as 36 packed 16x16 blocks.  Per 16-column panel, wave 0
+// eliminates the AUGMENTED 32x16 panel [A_d; I] in registers -- lane (i = lane&15, q = lane>>4) holds columns
+// q, q+4, q+8, q+12 of row i of both halves, multipliers travel by ds_bpermute -- which yields L_d and, from the
+// identity rows, inv(L_d)^T without a separate triangular inversion.  All four waves then apply
+// L_ib = A_ib inv(L_d)^T and the trailing update as 16x16x4 MFMAs.  The inverse is finished in place (each L21 block
+// is consumed exactly once by the recursive doubling), so no operand leaves LDS between load and store.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double bperm_f64(double v, int byte_index)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_index, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(byte_index, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// X: packed lower blocks A -> L -> inverse (in place); Xd: inv(L_bb), b = 0..7; Gs: inv(L_d)^T of the current panel
+__device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
+                                               double *X, double *Xd, double *Gs, int *bad_sp)
+{
+#define bad_s (*bad_sp)
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+
+#ifdef GPX_LEAF_STAMP
+    long long stamp[6];
+    stamp[0] = wall_clock64();
+#define GPX_STAMP(k) stamp[k] = wall_clock64()
+#else
+#define GPX_STAMP(k)
+#endif
+    if (t == 0) bad_s = 0;
+    {   // thread t carries element (t>>4, t&15) of every 16x16 block: 36 independent loads in flight, then 36 LDS stores
+        const int r = t >> 4, c = t & 15;
+        double v[36];
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) v[bi * (bi + 1) / 2 + bj] = A[(long)(16 * bi + r) * ld + 16 * bj + c];
+#pragma unroll
+        for (int b = 0; b < 36; ++b) X[b * XB + r * 17 + c] = v[b];
+    }
+    __syncthreads();
+    GPX_STAMP(1);
+
+#pragma unroll 1
+    for (int jb = 0; jb < 8; ++jb) {
+        if (wave == 0) {
+            double *Db = &X[xblk(jb, jb)];
+            double e[4], g[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                e[m] = Db[fr * 17 + fq + 4 * m];
+                g[m] = (fr == fq + 4 * m) ? 1.0 : 0.0;
+            }
+            int bad = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int mj = j >> 2, qj = j & 3;
+                double djj = readlane_f64(e[mj], qj * 16 + j);
+                if (!(djj > 0.0)) {
+                    if (bad == 0) bad = col_offset + 16 * jb + j + 1;
+                    djj = 1.0;
+                }
+                const double rinv = fast_rsqrt(djj);
+                const int src_row = (qj * 16 + fr) * 4;                       // lane (i, q_j): this row's entry of column j
+                const double ecol = e[mj], gcol = g[mj];                       // column j before it is scaled below
+                // all exchanges first (they do not depend on the pivot's reciprocal square root)
+                const double pl = bperm_f64(ecol, src_row);
+                const double pg = bperm_f64(gcol, src_row);
+                double pc[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) pc[m] = (m >= mj) ? bperm_f64(ecol, (qj * 16 + fq + 4 * m) * 4) : 0.0;   // A[c][j], c = fq + 4m
+                const double li = pl * rinv, lg = pg * rinv;                   // row j itself: d_jj * rinv = L_jj
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (m < mj) continue;                                       // columns left of the pivot are final
+                    const double lc = pc[m] * rinv;                             // L[c][j]
+                    const double ne = fma(-li, lc, e[m]), ng = fma(-lg, lc, g[m]);
+                    if (m > mj) {
+                        e[m] = ne;
+                        g[m] = ng;
+                    } else {                                                    // the pivot's own column group: select per lane
+                        e[m] = (fq > qj) ? ne : ((fq == qj) ? li : e[m]);
+                        g[m] = (fq > qj) ? ng : ((fq == qj) ? lg : g[m]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int c = fq + 4 * m;
+                Db[fr * 17 + c] = (c <= fr) ? e[m] : 0.0;
+                const double gv = (c >= fr) ? g[m] : 0.0;                        // inv(L_d)^T[fr][c] = inv(L_d)[c][fr]
+                Gs[fr * 17 + c] = gv;
+                Xd[jb * XB + c * 17 + fr] = gv;
+            }
+            if (bad && lane == 0 && bad_s == 0) bad_s = bad;
+        }
+        __syncthreads();
+        // ---- panel: L[ib][jb] = A[ib][jb] inv(L_d)^T ----
+        {
+            const double *Bb = &Gs[fq * 17 + fr];                  // B[k = 4kk + fq][col fr]
+            v4d res[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ib = jb + 1 + wave + 4 * q;
+                res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+                if (ib < 8) {
+                    const double *Ab = &X[xblk(ib, jb) + fr * 17 + fq];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        res[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[4 * kk], Bb[4 * kk * 17], res[q], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ib = jb + 1 + wave + 4 * q;
+                if (ib < 8) {
+                    double *Ob = &X[xblk(ib, jb)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Ob[(fq + 4 * r) * 17 + fr] = res[q][r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- trailing update: A[ib][kb] -= L[ib][jb] L[kb][jb]^T, jb < kb <= ib ----
+        {
+            const int nb = 7 - jb;
+            const int ntask = nb * (nb + 1) / 2;
+            for (int task = wave; task < ntask; task += 4) {
+                int ii = 0;
+                while ((ii + 1) * (ii + 2) / 2 <= task) ++ii;           // row within the trailing triangle
+                const int kk0 = task - ii * (ii + 1) / 2;
+                const int ib = jb + 1 + ii, kb = jb + 1 + kk0;
+                double *Cb = &X[xblk(ib, kb)];
+                const double *La = &X[xblk(ib, jb) + fr * 17 + fq];
+                const double *Lb = &X[xblk(kb, jb) + fr * 17 + fq];
+                v4d acc;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = Cb[(fq + 4 * r) * 17 + fr];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-La[4 * kk], Lb[4 * kk], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Cb[(fq + 4 * r) * 17 + fr] = acc[r];
+            }
+        }
+        __syncthreads();
+    }
+
+    // L -> global (zeros above the diagonal), diagonal, status
+    GPX_STAMP(2);
+    {
+        const int r = t >> 4, c = t & 15;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 8; ++bj) {
+                double val = 0.0;
+                if (bj < bi) val = X[xblk(bi, bj) + r * 17 + c];
+                else if (bj == bi) val = (c <= r) ? X[xblk(bi, bi) + r * 17 + c] : 0.0;
+                A[(long)(16 * bi + r) * ld + 16 * bj + c] = val;
+                if (bj == bi && c == r) diag_out[16 * bi + r] = val;
+            }
+    }
+    if (t == 0 && bad_s && *info == 0) *info = bad_s;
+    __syncthreads();
+    for (int e = t; e < 8 * 256; e += 256) {
+        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        X[xblk(b, b) + r * 17 + c] = Xd[b * XB + r * 17 + c];
+    }
+    __syncthreads();
+
+    GPX_STAMP(3);
+    // inverse, levels s = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
+    for (int s = 1; s <= 4; s <<= 1) {
+        const int npairs = 8 / (2 * s);
+        const int ntask = npairs * s * s;
+        v4d res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                const int rb = 2 * s * p + s + i, cb = 2 * s * p;
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int k = j; k < s; ++k) {
+                    const double *Lk = &X[xblk(rb, cb + k) + fr * 17 + fq];                  // L21[i][k]: A[row fr][4kk + fq]
+                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // X11[k][j]: B[4kk + fq][col fr]
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
+                }
+                res[q] = acc;
+            }
+        }
+        __syncthreads();   // all L21 reads are done before T lands in the same slots
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                const int rb = 2 * s * p + s, cb = 2 * s * p;
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int k = 0; k <= i; ++k) {
+                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];
+                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
+                }
+                res[q] = acc;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
+            }
+        }
+        __syncthreads();
+    }
+    GPX_STAMP(4);
+    {
+        const int r = t >> 4, c = t & 15;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 8; ++bj)
+                dinv[(16 * bi + r) * TILE + 16 * bj + c] = (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0;
+    }
+#ifdef GPX_LEAF_STAMP
+    __syncthreads();
+    stamp[5] = wall_clock64();
+    if (t == 0)
+        for (int k = 0; k < 6; ++k) dinv[16 + k] = (double)(stamp[k] - stamp[0]);   // diagnostic build only: lands in the zero block
+#endif
+#undef GPX_STAMP
+#undef bad_s
+}
+
+__global__ __launch_bounds__(256) void potrf_trtri128_mfma_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
+                                                                 int col_offset)
+{
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    __shared__ __attribute__((aligned(16))) double Xd[8 * XB];
+    __shared__ __attribute__((aligned(16))) double Gs[XB];
+    __shared__ int bad_s;
+    __builtin_amdgcn_s_setprio(3);
+    leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Xd, Gs, &bad_s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Leaf worker: ONE persistent workgroup that owns a whole CU for the duration of a factorisation and factors the
+// diagonal blocks k0..k1-1 as they become ready.  A leaf launched as an ordinary kernel lands on a CU that also runs a
+// bulk GEMM workgroup and crawls (fp64 VALU and the GEMM's fp64 MFMAs share the SIMD: 135 us average instead of 47 us
+// alone); the worker's LDS footprint (157 KB) keeps every GEMM workgroup (64 KB) off its CU.  The chain stream
+// replaces each leaf launch by a one-wave kernel that posts go = k+1 and waits for done = k+1; hand-offs are
+// agent-scope release/acquire on device memory.  Every wait has a wall-clock timeout, and an abort word, so all waves
+// reach their exit whatever the host does.
+//   flags[0] = go (blocks ready), flags[1] = done (blocks factored), flags[2] = abort, flags[3] = timeout seen
+// ------------------------------------------------------------------------------------------------
+constexpr long long LEAF_TIMEOUT_TICKS = 20LL * 100000000LL;   // 20 s of the 100 MHz wall clock
+
+// Polling uses RELAXED agent-scope loads: an acquire load is followed by an L2 invalidate (buffer_inv sc1) on every
+// iteration, which wipes the XCD's L2 under the GEMM workgroups sharing it a few million times per second.  One acquire
+// fence after the flag has been seen is enough.
+__device__ __forceinline__ bool leaf_wait_ge(unsigned long long *word, unsigned long long target, unsigned long long *flags)
+{
+    const long long t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+        if (__hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+        if (wall_clock64() - t0 > LEAF_TIMEOUT_TICKS) {
+            __hip_atomic_store(&flags[3], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(16);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return true;
+}
+
+__global__ __launch_bounds__(256) void leaf_worker_kernel(double *L, long ld, double *Dinv, double *diagL, int *info, int k0, int k1,
+                                                         unsigned long long *flags)
+{
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    __shared__ __attribute__((aligned(16))) double Xd[8 * XB];
+    __shared__ __attribute__((aligned(16))) double Gs[XB];
+    __shared__ __attribute__((aligned(16))) double pad_lds[7400];   // 59 KB of ballast: no 64-KB GEMM workgroup fits next to this one
+    __shared__ int bad_s;
+    __shared__ int go_s;
+    const int t = threadIdx.x;
+    if (k1 < 0) {   // never true: keeps the ballast allocated
+        pad_lds[t] = (double)t;
+        __syncthreads();
+        diagL[0] = pad_lds[(t + 1) & 255];
+    }
+    for (int k = k0; k < k1; ++k) {
+        if (t == 0) go_s = leaf_wait_ge(&flags[0], (unsigned long long)(k + 1), flags) ? 1 : 0;
+        __syncthreads();
+        if (!go_s) return;                                    // abort / timeout: uniform exit
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every thread: the block written by earlier kernels is visible
+        leaf_mfma_body(L + ((long)k * TILE) * ld + (long)k * TILE, ld, Dinv + (long)k * TILE * TILE, diagL + (long)k * TILE, info,
+                       k * TILE, X, Xd, Gs, &bad_s);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(&flags[1], (unsigned long long)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// chain-stream side of the hand-off: post "block k is ready", wait until the worker has factored it
+__global__ __launch_bounds__(64) void leaf_signal_wait_kernel(unsigned long long *flags, int k)
+{
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&flags[0], (unsigned long long)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        (void)leaf_wait_ge(&flags[1], (unsigned long long)(k + 1), flags);
+    }
+}
+
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
-    hipLaunchKernelGGL(potrf_trtri128_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
+    static const int leaf_mode = getenv("GPX_LEAF") ? atoi(getenv("GPX_LEAF")) : 1;   // 0 = register kernel, 1 = blocked MFMA kernel
+    if (leaf_mode == 0)
+        hipLaunchKernelGGL(potrf_trtri128_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
+    else
+        hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -370,12 +731,16 @@ constexpr int64_t CHOL_NBP = 8;
 // steps j in [j0,j1) of the diagonal square [B0,B1): leaf (factor + inverse), in-place TRSM leaf of the rows below
 // inside the square, rank-128 update of the square's remaining columns -- the latency-bound chain of small kernels
 static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
-                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof)
+                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, unsigned long long *worker_flags = nullptr)
 {
     (void)B0;
     for (int64_t j = j0; j < j1; ++j) {
-        GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
-                                  info_dev, (int)(j * TILE), s, prof));
+        if (worker_flags) {   // the persistent leaf worker factors block j; this stream only hands it over and waits
+            hipLaunchKernelGGL(leaf_signal_wait_kernel, dim3(1), dim3(64), 0, s, worker_flags, (int)j);
+            GPX_HIP(hipGetLastError());
+        } else
+            GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
+                                      info_dev, (int)(j * TILE), s, prof));
         const int64_t rows_below = B1 - (j + 1);
         if (rows_below <= 0) continue;
         double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
@@ -398,12 +763,24 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof)
+                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr)
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                   : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
-    const int64_t P = (nblk + CHOL_NBP - 1) / CHOL_NBP;
+    // outer panel boundaries (block units): GPX_CHOL_WIDE = w,r -> panels of w blocks while more than r blocks remain, then CHOL_NBP
+    std::vector<int64_t> Bs{0};
+    {
+        static const char *wenv = getenv("GPX_CHOL_WIDE");
+        int64_t wide = CHOL_NBP, until = 0;
+        if (wenv) { long a = 0, b = 0; if (sscanf(wenv, "%ld,%ld", &a, &b) == 2 && a >= 1) { wide = a; until = b; } }
+        while (Bs.back() < nblk) {
+            const int64_t rem = nblk - Bs.back();
+            Bs.push_back(std::min<int64_t>(nblk, Bs.back() + (rem > until ? wide : CHOL_NBP)));
+        }
+    }
+    const int64_t P = (int64_t)Bs.size() - 1;
+    auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P);
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
@@ -414,7 +791,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     }
     if (!s_bulk) s_bulk = s;
     int rc = 0;
+    // the leaf worker is bypassed under full profiling (its leaves are not separate launches that events could bracket)
+    static const int worker_mode = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;   // opt-in: measured slower overall
+    unsigned long long *wf = (lw && lw->stream && lw->flags && worker_mode && !(prof && prof->level >= 2)) ? lw->flags : nullptr;
+    unsigned long long *wf_chain = (worker_mode == 2) ? nullptr : wf;   // experiment: 2 = worker resident but idle, ordinary leaves
     auto run = [&]() -> int {
+        if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
         // Per outer panel p the main stream runs, in order:
         //   TRSM of rows [B1,B2) of panel p + update of panel p+1's diagonal square  -> event: the side stream starts
         //   TRSM of the remaining rows of panel p, update of the remaining rows of panel p+1's columns,
@@ -423,11 +805,16 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // CUs, pure latency) underneath all of that.
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
-        GPX_TRY(chol_square_steps(L, ld, 0, std::min<int64_t>(CHOL_NBP, nblk), 0, std::min<int64_t>(CHOL_NBP, nblk), Dinv, diagL,
-                                  info_dev, s_pan, prof));
+        if (wf) {
+            GPX_HIP(hipStreamWaitEvent(lw->stream, ev0, 0));
+            hipLaunchKernelGGL(leaf_worker_kernel, dim3(1), dim3(256), 0, lw->stream, L, (long)ld, Dinv, diagL, info_dev, 0, (int)nblk, wf);
+            GPX_HIP(hipGetLastError());
+        }
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL,
+                                  info_dev, s_pan, prof, wf_chain));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
-            const int64_t B0 = p * CHOL_NBP, B1 = std::min<int64_t>(B0 + CHOL_NBP, nblk), B2 = std::min<int64_t>(B1 + CHOL_NBP, nblk);
+            const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) break;
             const int64_t K = (B1 - B0) * TILE;
@@ -441,7 +828,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
             if (B2 < nblk) {
                 // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
                 GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
@@ -456,13 +843,69 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
                 }
             }
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
         return 0;
     };
-    rc = run();
+    // Schedule 2: the side stream owns a panel completely -- diagonal chain, then the TRSM of ALL rows below -- and
+    // runs it underneath the previous panel's bulk SYRK (which never touches this panel's columns); the main stream
+    // only issues the two trailing updates per panel: the next panel's columns first (that is what releases the side
+    // stream), then the bulk.
+    auto run2 = [&]() -> int {
+        if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
+        GPX_HIP(hipEventRecord(ev0, s));
+        GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
+        if (wf) {
+            GPX_HIP(hipStreamWaitEvent(lw->stream, ev0, 0));
+            hipLaunchKernelGGL(leaf_worker_kernel, dim3(1), dim3(256), 0, lw->stream, L, (long)ld, Dinv, diagL, info_dev, 0, (int)nblk, wf);
+            GPX_HIP(hipGetLastError());
+        }
+        for (int64_t p = 0; p < P; ++p) {
+            const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
+            // side stream: panel p (its columns are complete once ev_next[p-1] has fired)
+            if (p > 0) GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p - 1], 0));
+            GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
+            if (B1 < nblk) GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s_pan, prof));
+            GPX_HIP(hipEventRecord(ev_pf[p], s_pan));
+            if (B1 >= nblk) break;
+            // main stream: trailing updates with panel p
+            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));
+            const int64_t K = (B1 - B0) * TILE;
+            const double *Pall = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows >= B1
+            // next panel's columns: its diagonal square (lower tiles) and everything below it
+            GPX_TRY(launch_gemm_nt(Pall, ld, Pall, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
+                                   -1.0, 1.0, 1, s, prof));
+            if (B2 < nblk) {
+                const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
+                GPX_TRY(launch_gemm_nt(Pr, ld, Pall, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
+                                       K, -1.0, 1.0, 0, s, prof));
+            }
+            GPX_HIP(hipEventRecord(ev_next[p], s));
+            if (B2 < nblk) {
+                const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;
+                GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
+                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+            }
+        }
+        GPX_HIP(hipStreamWaitEvent(s, ev_pf[P - 1], 0));
+        return 0;
+    };
+    static const int sched = getenv("GPX_CHOL_SCHED") ? atoi(getenv("GPX_CHOL_SCHED")) : 1;   // 2 = opt-in experiment, measured slower
+    rc = (sched == 2) ? run2() : run();
+    if (wf && (rc || worker_mode == 2)) {   // the host gave up half-way: release the worker and whoever waits for it
+        const unsigned long long one = 1;
+        (void)hipMemcpy(wf + 2, &one, sizeof(one), hipMemcpyHostToDevice);
+    }
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
+    if (wf) {
+        (void)hipStreamSynchronize(lw->stream);
+        unsigned long long timed_out = 0;
+        if (hipMemcpy(&timed_out, wf + 3, sizeof(timed_out), hipMemcpyDeviceToHost) == hipSuccess && timed_out && !rc) {
+            gpx_set_error("Cholesky leaf worker hand-off timed out");
+            rc = GPX_ERR_HIP;
+        }
+    }
     if (s_bulk != s) (void)hipStreamSynchronize(s_bulk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);

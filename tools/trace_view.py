@@ -5,10 +5,11 @@ rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # the last gram_kernel with lower-only (fit) marks the start of a fit: take the LAST fit in the trace
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("gram_kernel")]
-start = idx[-2] if len(idx) >= 2 else idx[-1]   # fit gram then predict gram alternate; the second to last is the fit's
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # 0 = last fit in the trace, 1 = the one before, ...
+start = idx[-2 - 2 * back] if len(idx) >= 2 + 2 * back else idx[-1]   # fit gram then predict gram alternate
 t0 = int(rows[start]["Start_Timestamp"])
 lim = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-short = {"gemm_nt_f64_kernel": "gemm", "potrf128_kernel": "POTRF", "trtri128_kernel": "TRTRI", "trsv": "trsv", "gram": "gram"}
+short = {"leaf_signal_wait": "LEAFWAIT", "leaf_worker": "WORKER", "gemm_nt_f64_kernel": "gemm", "potrf128_kernel": "POTRF", "trtri128_kernel": "TRTRI", "trsv": "trsv", "gram": "gram"}
 n = 0
 for r in rows[start:]:
     name = r["Kernel_Name"]
