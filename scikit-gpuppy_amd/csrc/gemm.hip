@@ -170,11 +170,17 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     //   slices   : fragments double buffered in registers one 4-deep k-slice ahead of the MFMAs
     //   barrier  : BEFORE the last slice's MFMAs, so the first fragments of stage t+1 are read while they run
     double fa[2][WM], fb[2][WN];
+    // volatile: keeps every fragment read a ds_read_b64.  Left alone, the compiler merges pairs into ds_read2st64_b64,
+    // which the LDS services in four 16-lane groups against 32 banks; the swizzle (built for ds_read_b64's two 32-lane
+    // halves against 64 banks) then conflicts 2-way and a pair costs 16 LDS cycles instead of 4
+    // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5 measured on the merged form).
+    typedef const volatile __attribute__((address_space(3))) double lds_vdouble;
+    lds_vdouble *vsm = (lds_vdouble *)smem;
 #define GPX_LOAD_FRAGS(SET, BUFOFF, KK)                                                \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
-        fa[SET][i_] = smem[(BUFOFF) + a_row + i_ * 256 + koff[KK]];                    \
+        fa[SET][i_] = vsm[(BUFOFF) + a_row + i_ * 256 + koff[KK]];                     \
     _Pragma("unroll") for (int i_ = 0; i_ < WN; ++i_)                                  \
-        fb[SET][i_] = smem[(BUFOFF) + b_row + i_ * 256 + koff[KK]];
+        fb[SET][i_] = vsm[(BUFOFF) + b_row + i_ * 256 + koff[KK]];
 #define GPX_MMA(SET)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
         _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
