@@ -31,6 +31,13 @@ __device__ __forceinline__ void gpx_mma(v4d &acc, double a, double b)
     if constexpr (ASM) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
     else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
 }
+// pin a wave-uniform pointer into SGPRs (so that global_load_lds takes the "SGPR base + 32-bit VGPR offset" form)
+__device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
+{
+    const unsigned long v = reinterpret_cast<unsigned long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char *>(((unsigned long)hi << 32) | lo);
+}
 __device__ __forceinline__ void gpx_acc_fence(v4d &a0, v4d &a1, v4d &a2, v4d &a3, v4d &a4, v4d &a5, v4d &a6, v4d &a7)
 {
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5), "+a"(a6), "+a"(a7));
@@ -88,34 +95,41 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     const int fr = lane & 15, fq = lane >> 4;
 
     // ---- LDS-DMA staging: instruction j of a tile covers rows 8j..8j+7; lane -> (row 8j + lane>>3, granule lane&7)
+    // The source address of a DMA instruction is (uniform 64-bit base of the tile row + k offset: SGPRs, advanced by the
+    // scalar unit) + (32-bit per-lane byte offset inside the tile: a VGPR that never changes) -- no vector arithmetic
+    // per stage (fp64 MFMAs do not co-issue with other VALU work: SQ_VALU_MFMA_COEXEC_CYCLES = 0).
     const int drow = lane >> 3;
-    const double *Ag[(BTM / 8 + 3) / 4], *Bg[(BTN / 8 + 3) / 4];
+    const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda);
+    const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb);
+    unsigned aoff[(BTM / 8 + 3) / 4], boff[(BTN / 8 + 3) / 4];
 #pragma unroll
     for (int u = 0; u < (BTM / 8 + 3) / 4; ++u) {
         const int j = wave + 4 * u, row = 8 * j + drow;
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        Ag[u] = A + ((long)by * BTM + row) * lda + 2 * c;
+        aoff[u] = (unsigned)(((long)row * lda + 2 * c) * 8);
     }
 #pragma unroll
     for (int u = 0; u < (BTN / 8 + 3) / 4; ++u) {
         const int j = wave + 4 * u, row = 8 * j + drow;
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        Bg[u] = B + ((long)bx * BTN + row) * ldb + 2 * c;
+        boff[u] = (unsigned)(((long)row * ldb + 2 * c) * 8);
     }
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
 #define GPX_DMA_STAGE(BUF, KT)                                                                                      \
     {                                                                                                               \
+        const char *ak_ = gpx_uniform_ptr(Abase + (long)(KT) * (GEMM_BK * 8));                                     \
+        const char *bk_ = gpx_uniform_ptr(Bbase + (long)(KT) * (GEMM_BK * 8));                                     \
         _Pragma("unroll") for (int u_ = 0; u_ < (BTM / 8 + 3) / 4; ++u_) {                                          \
             const int j_ = wave + 4 * u_;                                                                           \
             if (BTM / 8 % 4 == 0 || j_ < BTM / 8)                                                                   \
-                __builtin_amdgcn_global_load_lds((glb_void *)(Ag[u_] + (long)(KT) * GEMM_BK),                       \
+                __builtin_amdgcn_global_load_lds((glb_void *)(ak_ + aoff[u_]),                                      \
                                                  (lds_void *)(smem + (BUF) * STAGE + j_ * 128), 16, 0, 0);          \
         }                                                                                                           \
         _Pragma("unroll") for (int u_ = 0; u_ < (BTN / 8 + 3) / 4; ++u_) {                                          \
             const int j_ = wave + 4 * u_;                                                                           \
             if (BTN / 8 % 4 == 0 || j_ < BTN / 8)                                                                   \
-                __builtin_amdgcn_global_load_lds((glb_void *)(Bg[u_] + (long)(KT) * GEMM_BK),                       \
+                __builtin_amdgcn_global_load_lds((glb_void *)(bk_ + boff[u_]),                                      \
                                                  (lds_void *)(smem + (BUF) * STAGE + BTM * 16 + j_ * 128), 16, 0, 0); \
         }                                                                                                           \
     }
@@ -187,16 +201,41 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             gpx_mma<BIG>(acc[i_][j_], fa[SET][i_], fb[SET][j_]);
 
     GPX_LOAD_FRAGS(0, 0, 0)
+    if constexpr (!BIG) {
+        // two buffers, the stage loop unrolled by two: buffer offsets are immediates of the ds_read_b64 / M0 values, so the
+        // steady state issues no vector instruction besides MFMAs, fragment reads and the DMA
+#define GPX_KSTEP(CUR_OFF, NXT_OFF, NXT_BUF, KT)                                        \
+        {                                                                               \
+            const bool has_next_ = (KT) + 1 < nk;                                       \
+            if (has_next_) GPX_DMA_STAGE(NXT_BUF, (KT) + 1)                             \
+            GPX_LOAD_FRAGS(1, CUR_OFF, 1)                                               \
+            GPX_MMA(0)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            GPX_LOAD_FRAGS(0, CUR_OFF, 2)                                               \
+            GPX_MMA(1)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            GPX_LOAD_FRAGS(1, CUR_OFF, 3)                                               \
+            GPX_MMA(0)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+            __syncthreads();                                                            \
+            if (has_next_) { GPX_LOAD_FRAGS(0, NXT_OFF, 0) }                            \
+            GPX_MMA(1)                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }
+        for (int kt = 0; kt < nk; kt += 2) {
+            GPX_KSTEP(0, STAGE, 1, kt)
+            if (kt + 1 < nk) GPX_KSTEP(STAGE, 0, 0, kt + 1)
+        }
+#undef GPX_KSTEP
+    } else {
     int cur = 0;                                   // buffer index of stage kt
     for (int kt = 0; kt < nk; ++kt) {
         const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
         const int cur_off = cur * STAGE, nxt_off = nxt * STAGE;
         const bool has_next = kt + 1 < nk;
-        if constexpr (BIG) {
+        {
             const int far = (nxt + 1 == NBUF) ? 0 : nxt + 1;
             if (kt + 2 < nk) GPX_DMA_STAGE(far, kt + 2)
-        } else {
-            if (has_next) GPX_DMA_STAGE(nxt, kt + 1)
         }
         GPX_LOAD_FRAGS(1, cur_off, 1)
         GPX_MMA(0)
@@ -207,19 +246,16 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         GPX_LOAD_FRAGS(1, cur_off, 3)
         GPX_MMA(0)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (BIG) {
-            // stage kt+1 must have landed; the DMA of stage kt+2 (the NDMA youngest operations) may stay in flight
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            __syncthreads();
-        }
+        // stage kt+1 must have landed; the DMA of stage kt+2 (the NDMA youngest operations) may stay in flight
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         if (has_next) { GPX_LOAD_FRAGS(0, nxt_off, 0) }
         GPX_MMA(1)
         __builtin_amdgcn_sched_barrier(0);
         cur = nxt;
+    }
     }
 #undef GPX_LOAD_FRAGS
 #undef GPX_MMA
