@@ -114,8 +114,13 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         boff[u] = (unsigned)(((long)row * ldb + 2 * c) * 8);
     }
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
+    // LDS-DMA as inline asm: "global_load_lds_dwordx4 voffset, sbase" with the LDS destination in M0.  (The builtin
+    // re-materialises a 64-bit vector address per instruction inside the unrolled loop: 8 VALU adds per stage that the
+    // fp64 MFMA pipe cannot overlap.)  hipcc does not see these loads, so every barrier that publishes a stage is
+    // preceded by an explicit s_waitcnt vmcnt.
+    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) double *)smem;
+#define GPX_DMA_ONE(SBASE, VOFF, LDSBYTES)                                                                           \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(LDSBYTES), "v"(VOFF), "s"(SBASE) : "memory");
 #define GPX_DMA_STAGE(BUF, KT)                                                                                      \
     {                                                                                                               \
         const char *ak_ = gpx_uniform_ptr(Abase + (long)(KT) * (GEMM_BK * 8));                                     \
@@ -123,14 +128,12 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         _Pragma("unroll") for (int u_ = 0; u_ < (BTM / 8 + 3) / 4; ++u_) {                                          \
             const int j_ = wave + 4 * u_;                                                                           \
             if (BTM / 8 % 4 == 0 || j_ < BTM / 8)                                                                   \
-                __builtin_amdgcn_global_load_lds((glb_void *)(ak_ + aoff[u_]),                                      \
-                                                 (lds_void *)(smem + (BUF) * STAGE + j_ * 128), 16, 0, 0);          \
+                GPX_DMA_ONE(ak_, aoff[u_], __builtin_amdgcn_readfirstlane(lds_base + 8u * (unsigned)((BUF) * STAGE + j_ * 128))) \
         }                                                                                                           \
         _Pragma("unroll") for (int u_ = 0; u_ < (BTN / 8 + 3) / 4; ++u_) {                                          \
             const int j_ = wave + 4 * u_;                                                                           \
             if (BTN / 8 % 4 == 0 || j_ < BTN / 8)                                                                   \
-                __builtin_amdgcn_global_load_lds((glb_void *)(bk_ + boff[u_]),                                      \
-                                                 (lds_void *)(smem + (BUF) * STAGE + BTM * 16 + j_ * 128), 16, 0, 0); \
+                GPX_DMA_ONE(bk_, boff[u_], __builtin_amdgcn_readfirstlane(lds_base + 8u * (unsigned)((BUF) * STAGE + BTM * 16 + j_ * 128))) \
         }                                                                                                           \
     }
 
@@ -165,7 +168,8 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     } else {
-        __syncthreads();   // (hipcc drains the DMA with vmcnt(0) before the barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0 has landed (the asm DMA is invisible to hipcc)
+        __syncthreads();
     }
 
     // fragment addresses: row-local swizzle term depends on the lane only ((row>>1)&7 == (fr>>1)&7 because the
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             GPX_LOAD_FRAGS(1, CUR_OFF, 3)                                               \
             GPX_MMA(0)                                                                  \
             __builtin_amdgcn_sched_barrier(0);                                          \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            \
             __syncthreads();                                                            \
             if (has_next_) { GPX_LOAD_FRAGS(0, NXT_OFF, 0) }                            \
             GPX_MMA(1)                                                                  \
