@@ -300,7 +300,7 @@ extern "C" int gpx_stamp_read(unsigned long long *out)
 constexpr double SMALL_GRID_TILES = 192.0;
 
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
-                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof)
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles)
 {
     if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
@@ -342,7 +342,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     else if (big_mode == 4 && !lower_only) GPX_LAUNCH(2, 2);
     else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 1 && N % 256 == 0) GPX_LAUNCH(4, 8);
     else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 2 && M % 256 == 0) GPX_LAUNCH(8, 4);
-    else if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
+    else if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);

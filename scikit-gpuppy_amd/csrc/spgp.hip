@@ -35,7 +35,55 @@ struct gpx_spgp {
     double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad]
     double *outd = nullptr;  // [8] scalar results
     int *info = nullptr;
+    static constexpr int SPLIT = 8;                 // K-chunks of the tall-skinny product W^T W (K = N)
+    hipStream_t split_stream[SPLIT] = {};
+    hipEvent_t split_ev[SPLIT + 1] = {};
+    double *split_buf = nullptr;                    // [SPLIT - 1][mpad, mpad] partial products
 };
+
+// out[i] += sum_s part[s][i]   (lower tiles matter only; summing everything keeps the kernel trivial)
+__global__ __launch_bounds__(256) void add_partials_kernel(double *__restrict__ out, const double *__restrict__ part, long elems, int nparts)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= elems) return;
+    v2d acc = *reinterpret_cast<const v2d *>(out + i);
+    for (int s = 0; s < nparts; ++s) {
+        const v2d p = *reinterpret_cast<const v2d *>(part + (long)s * elems + i);
+        acc.x += p.x;
+        acc.y += p.y;
+    }
+    *reinterpret_cast<v2d *>(out + i) = acc;
+}
+
+// C (lower tiles) <- beta C + Wt Wt^T for the [mpad, npad] row-major Wt: the contraction runs over N = 262144 at BASELINE
+// config 5 while C has only 136 lower 128x128 tiles, so it is split into K-chunks that run concurrently on their own
+// streams (chunk 0 accumulates into C, the others into scratch) and are summed afterwards.
+static int spgp_wtw(gpx_spgp *h, double *C, double beta)
+{
+    hipStream_t s = h->stream;
+    const int64_t np = h->npad, mp = h->mpad;
+    int64_t chunk = round_up((np + gpx_spgp::SPLIT - 1) / gpx_spgp::SPLIT, TILE);
+    const int nchunks = (int)((np + chunk - 1) / chunk);
+    if (np < 16384 || nchunks < 2 || !h->split_buf)
+        return launch_gemm_nt(h->Wt, np, h->Wt, np, C, mp, mp, mp, np, 1.0, beta, 1, s, nullptr);
+    GPX_HIP(hipEventRecord(h->split_ev[gpx_spgp::SPLIT], s));
+    for (int c = 0; c < nchunks; ++c) {
+        const int64_t k0 = c * chunk, kc = std::min<int64_t>(chunk, np - k0);
+        hipStream_t sc = (c == 0) ? s : h->split_stream[c];
+        if (c > 0) GPX_HIP(hipStreamWaitEvent(sc, h->split_ev[gpx_spgp::SPLIT], 0));
+        double *Cc = (c == 0) ? C : h->split_buf + (int64_t)(c - 1) * mp * mp;
+        GPX_TRY(launch_gemm_nt(h->Wt + k0, np, h->Wt + k0, np, Cc, mp, mp, mp, kc, 1.0, (c == 0) ? beta : 0.0, 1, sc, nullptr, 1));
+        if (c > 0) {
+            GPX_HIP(hipEventRecord(h->split_ev[c], sc));
+            GPX_HIP(hipStreamWaitEvent(s, h->split_ev[c], 0));
+        }
+    }
+    // the partial buffers' strictly-upper tiles are never written: they were zeroed once at allocation and stay zero
+    const long elems = (long)mp * mp;
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, s, C, (const double *)h->split_buf, elems, nchunks - 1);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
 
 // out[j][i] = in[i][j] * scale[i]   (in: [rows, ldin] -> out: [cols, ldout]; 32x32 LDS tiles)
 __global__ __launch_bounds__(256) void scale_transpose_kernel(const double *__restrict__ in, long ldin, long rows, long cols,
@@ -129,6 +177,11 @@ extern "C" void gpx_spgp_free(gpx_spgp *h)
                     h->ilam, h->va, h->vb, h->vc, h->ma, h->mb, h->mzero, h->beta, h->mscr, h->outd};
     for (void *p : bufs) dfree(p);
     if (h->info) (void)hipFree(h->info);
+    for (int c = 1; c < gpx_spgp::SPLIT; ++c)
+        if (h->split_stream[c]) { (void)hipStreamSynchronize(h->split_stream[c]); (void)hipStreamDestroy(h->split_stream[c]); }
+    for (int c = 0; c <= gpx_spgp::SPLIT; ++c)
+        if (h->split_ev[c]) (void)hipEventDestroy(h->split_ev[c]);
+    dfree(h->split_buf);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -178,6 +231,12 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
     GPX_TRY(dalloc(&h->outd, 8));
     GPX_HIP(hipMalloc((void **)&h->info, sizeof(int)));
+    if (np >= 16384) {   // split-K machinery of spgp_wtw
+        GPX_TRY(dalloc(&h->split_buf, (int64_t)(gpx_spgp::SPLIT - 1) * mp * mp));
+        GPX_HIP(hipMemsetAsync(h->split_buf, 0, sizeof(double) * (gpx_spgp::SPLIT - 1) * mp * mp, s));
+        for (int c = 1; c < gpx_spgp::SPLIT; ++c) GPX_HIP(hipStreamCreateWithFlags(&h->split_stream[c], hipStreamNonBlocking));
+        for (int c = 0; c <= gpx_spgp::SPLIT; ++c) GPX_HIP(hipEventCreateWithFlags(&h->split_ev[c], hipEventDisableTiming));
+    }
     // raw inputs are staged through Z / LB (both overwritten below)
     GPX_HIP(hipMemcpyAsync(h->Z, x, sizeof(double) * n * d, hipMemcpyDefault, s));
     GPX_HIP(hipMemcpyAsync(h->LB, xb, sizeof(double) * m * d, hipMemcpyDefault, s));
@@ -202,7 +261,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     // W^T = (Lambda^-1/2 K_NM)^T ;  B~ = K_M + 1e-5 I + W^T W                   (:856-858)
     GPX_TRY(spgp_transpose(h, h->Knm, h->ilam, h->Wt));
     GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 1e-5, 1, 2, h->LB, mp, mp, mp, s, nullptr));
-    GPX_TRY(launch_gemm_nt(h->Wt, np, h->Wt, np, h->LB, mp, mp, mp, np, 1.0, 1.0, 1, s, nullptr));
+    GPX_TRY(spgp_wtw(h, h->LB, 1.0));
     GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
     GPX_TRY(chol_factor(h->LB, mp, h->mblk, h->DinvB, h->diagB, h->info, s, nullptr, nullptr, nullptr));
     GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -304,7 +363,7 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
         GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->va, h->vb, nullptr, s));                       // vb = y / sqrt(ep)
         GPX_TRY(spgp_transpose(h, h->Z, h->va, h->Wt));                                             // Wt = V / sqrt(ep)  [M, N]
         GPX_TRY(launch_set_identity(A, mp, mp, s));
-        GPX_TRY(launch_gemm_nt(h->Wt, np, h->Wt, np, A, mp, mp, mp, np, 1.0, h->vt, 1, s, nullptr));   // A = vt I + V V^T
+        GPX_TRY(spgp_wtw(h, A, h->vt));                                                             // A = vt I + V V^T
         GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
         GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));  // Lm
         GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V y

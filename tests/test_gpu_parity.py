@@ -605,3 +605,34 @@ def test_spgp_full_size_properties():
     md, vd = de.estimate_many(xs_s)
     np.testing.assert_allclose(ms, md, rtol=0, atol=5e-3)
     np.testing.assert_allclose(vs, vd, rtol=0, atol=5e-3)
+
+
+def test_spgp_split_k_path():
+    """N >= 16384 takes the split-K product for K_MN Lambda^-1 K_NM (eight concurrent K-chunks + a summation pass):
+    Snelson's likelihood against the oracle's O(N m^2) restatement, predictions against a numpy transcription of the
+    Woodbury algebra (no N x N matrix on either side)."""
+    from scipy.linalg import cholesky, solve_triangular
+    rng = np.random.RandomState(31)
+    N, d, m = 20000, 4, 300
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    th_gc = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    xb = rng.uniform(0, 10, (m, d))
+    th = np.concatenate([th_gc, xb.ravel()])
+    xs = rng.uniform(0, 10, (50, d))
+    cov = sk.SPGPCovariance(m)
+    tc = t - t.mean()
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(orc.spgp_nll(x, tc, th, m), rel=1e-8)
+    gp = sk.GaussianProcess(x, t, cov, th.copy())
+    mu, var = gp.estimate_many(xs)
+    Knm, Km = orc.gram_ij(x, xb, th_gc), orc.gram_ij(xb, xb, th_gc)
+    Lm = cholesky(Km + 1e-5 * np.eye(m), lower=True)
+    lam = 2.0 + 0.01 - (solve_triangular(Lm, Knm.T, lower=True) ** 2).sum(0)
+    B = Km + 1e-5 * np.eye(m) + (Knm.T / lam).dot(Knm)
+    Lb = cholesky(B, lower=True)
+    beta = np.linalg.solve(B, (Knm.T / lam).dot(tc))
+    Ks = orc.gram_ij(xs, xb, th_gc)
+    want_mu = Ks.dot(beta) + t.mean()
+    want_var = 2.01 - (solve_triangular(Lm, Ks.T, lower=True) ** 2).sum(0) + (solve_triangular(Lb, Ks.T, lower=True) ** 2).sum(0)
+    np.testing.assert_allclose(mu, want_mu, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(var, want_var, rtol=0, atol=2e-6)
