@@ -317,7 +317,7 @@ extern "C" void gpx_free(gpx_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->prof.destroy();
     if (h->external_factor) { h->L = nullptr; h->Dinv = nullptr; h->diagL = nullptr; }
-    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
+    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV, h->DinvT};
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) (void)hipFree(h->info_dev);
@@ -708,9 +708,19 @@ static int ensure_prop_buffers(gpx_handle *h)
     return 0;
 }
 
+// how many new-u propagations are answered by triangular solves (two recursive TRSMs on a 128-row block, 9 ms at
+// N = 16384) before K^-1 is materialised (66 ms once, then 0.6 ms per new u; break-even after 8 calls): a single
+// propagate_GA after a fit never pays for K^-1, an inverse-propagation loop switches over after a few calls
+static int approx_solve_limit()
+{
+    static const int v = getenv("GPX_APPROX_SOLVE_CALLS") ? atoi(getenv("GPX_APPROX_SOLVE_CALLS")) : 6;
+    return v;
+}
+
 static int prepare_u(gpx_handle *h, const double *u)
 {
-    GPX_TRY(ensure_kinv(h));
+    const bool by_solves = !h->Kinv && h->approx_solves < approx_solve_limit();
+    if (!by_solves) GPX_TRY(ensure_kinv(h));
     GPX_TRY(ensure_prop_buffers(h));
     double uh[GPX_MAX_D];
     GPX_HIP(hipMemcpy(uh, u, sizeof(double) * h->d, hipMemcpyDefault));
@@ -720,8 +730,20 @@ static int prepare_u(gpx_handle *h, const double *u)
     GPX_HIP(hipMemcpyAsync(udev_ptr(h), uh, sizeof(double) * h->d, hipMemcpyHostToDevice, s));
     GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
     GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
-    // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6
-    GPX_TRY(launch_kinv_pass(h->Kinv, h->npad, h->npad, h->d + 1, h->V, h->KV, s, &h->prof));
+    if (by_solves) {
+        // KV = V K^-1 = (V L^-T) L^-1 on the 128-row block, no K^-1
+        if (!h->DinvT) {
+            GPX_TRY(dalloc(&h->DinvT, h->nblk * (int64_t)TILE * TILE));
+            GPX_TRY(launch_transpose_factor(h->L, h->npad, h->nblk, h->Dinv, h->DinvT, s));
+        }
+        GPX_HIP(hipMemcpyAsync(h->KV, h->V, sizeof(double) * TILE * h->npad, hipMemcpyDeviceToDevice, s));
+        GPX_TRY(trsm_right_lt(h->KV, h->npad, TILE, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof));
+        GPX_TRY(trsm_right_ln(h->KV, h->npad, TILE, h->L, h->npad, h->DinvT, 0, h->nblk, s, &h->prof));
+        ++h->approx_solves;
+    } else {
+        // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6
+        GPX_TRY(launch_kinv_pass(h->Kinv, h->npad, h->npad, h->d + 1, h->V, h->KV, s, &h->prof));
+    }
     memcpy(h->u, uh, sizeof(double) * h->d);
     h->have_u = true;
     return 0;

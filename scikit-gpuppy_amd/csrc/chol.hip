@@ -697,6 +697,59 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Right solve with L itself (not L^T):  Z[0:rows, c0:c1) <- Z[0:rows, c0:c1) * L[c0:c1, c0:c1]^-1.
+// The GEMM contracts along contiguous k only, so the update  Z_left -= Z_right L[right, left]  needs L^T blocks:
+// launch_transpose_factor stores them once in the (otherwise unused) strictly-upper 128-tiles of the factor's own
+// array -- U[j][c] = L[c][j] -- and the transposed inverse diagonal blocks in DinvT.  Together with trsm_right_lt
+// this gives  V K^-1 = (V L^-T) L^-1  for a block of right-hand-side ROWS without ever forming K^-1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_factor_kernel(double *L, long ld, long nblk, const double *Dinv, double *DinvT)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const long bi = blockIdx.y, bj = blockIdx.x;               // 32-blocks of the padded matrix; blockIdx.z == 1: the Dinv tiles
+    if (blockIdx.z == 1) {
+        if (bj >= 4) return;                                    // Dinv is [nblk*128][128]: 4 column blocks
+        const long b = bi >> 2, ri = (bi & 3) * 32, cj = bj * 32;
+        const double *src = Dinv + b * TILE * TILE;
+        double *dst = DinvT + b * TILE * TILE;
+        for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(ri + r) * TILE + cj + tx];
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) dst[(cj + r) * TILE + ri + tx] = tile[tx][r];
+        return;
+    }
+    if ((bj >> 2) >= (bi >> 2)) return;                         // strictly-lower 128-tiles only
+    for (int r = ty; r < 32; r += 8) tile[r][tx] = L[(bi * 32 + r) * ld + bj * 32 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) L[(bj * 32 + r) * ld + bi * 32 + tx] = tile[tx][r];
+}
+
+int launch_transpose_factor(double *L, int64_t ld, int64_t nblk, const double *Dinv, double *DinvT, hipStream_t s)
+{
+    const unsigned nb32 = (unsigned)(nblk * 4);
+    hipLaunchKernelGGL(transpose_factor_kernel, dim3(nb32, nb32, 2), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, DinvT);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int trsm_right_ln(double *Z, int64_t ldz, int64_t rows, const double *LU, int64_t ldl, const double *DinvT,
+                  int64_t c0, int64_t c1, hipStream_t s, Profiler *prof)
+{
+    const int64_t nb = c1 - c0;
+    if (nb <= 0 || rows <= 0) return 0;
+    if (nb == 1) {
+        double *Zc = Z + c0 * TILE;
+        return launch_gemm_nt(Zc, ldz, DinvT + c0 * (int64_t)TILE * TILE, TILE, Zc, ldz, rows, TILE, TILE, 1.0, 0.0, 0, s, prof);
+    }
+    const int64_t h = split_point(nb), cm = c0 + h;
+    GPX_TRY(trsm_right_ln(Z, ldz, rows, LU, ldl, DinvT, cm, c1, s, prof));
+    // Z[:, c0:cm) -= Z[:, cm:c1) * L[cm:c1, c0:cm)  with the B operand read from the transposed copy U[c0:cm, cm:c1)
+    GPX_TRY(launch_gemm_nt(Z + cm * TILE, ldz, LU + (c0 * TILE) * ldl + cm * TILE, ldl, Z + c0 * TILE, ldz, rows,
+                           (cm - c0) * TILE, (c1 - cm) * TILE, -1.0, 1.0, 0, s, prof));
+    return trsm_right_ln(Z, ldz, rows, LU, ldl, DinvT, c0, cm, s, prof);
+}
+
 static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv, double *diagL, int *info_dev,
                     hipStream_t s, Profiler *prof)
 {

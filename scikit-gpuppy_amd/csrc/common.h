@@ -100,6 +100,8 @@ struct gpx_handle {
     int64_t small_elems = 0;
 
     // propagate cache (keyed on u)
+    double *DinvT = nullptr;    // transposed inverse diagonal blocks; set once the factor's upper tiles hold L^T (solve path of the propagation)
+    int approx_solves = 0;      // new-u propagations served by triangular solves so far (K^-1 is built after a few)
     bool have_u = false;
     double u[GPX_MAX_D];
     double *V = nullptr;        // [ncolV, npad] column-major block of C, J_k, hh_k, tr
@@ -125,6 +127,9 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B
                       int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
+                  int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
+int launch_transpose_factor(double *L, int64_t ld, int64_t nblk, const double *Dinv, double *DinvT, hipStream_t s);
+int trsm_right_ln(double *Z, int64_t ldz, int64_t rows, const double *LU, int64_t ldl, const double *DinvT,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);

@@ -302,6 +302,38 @@ class ShardedGaussianProcess(object):
         return full[0] + self.meant, full[1]
 
 
+    # ---- uncertainty propagation on the replicated factor (last row) ------------------------
+    def propagate_GA(self, u, Sigma):
+        """UncertaintyPropagationApprox.propagate_GA on this rank's copy of the factor
+        (skgpuppy/UncertaintyPropagation.py:381-523): every rank holds the complete L after the panel broadcasts, so a
+        single propagation needs no exchange at all -- it runs as two triangular solves on the right-hand-side block
+        (no K^-1: 34 GB at N = 65536 stay unallocated).  Returns (mean + meant, variance)."""
+        from . import _gpx
+        u = _gpx.f64(u)
+        S = _gpx.f64(Sigma)
+        out = [ctypes.c_double() for _ in range(4)]
+        _gpx.check(_gpx.lib.gpx_propagate_approx(self._h, _gpx.ptr(u), _gpx.ptr(S), *[ctypes.byref(o) for o in out]),
+                   "gpx_propagate_approx")
+        return out[0].value + self.meant, out[1].value
+
+    def propagate_many(self, us, Sigmas):
+        """many independent propagations (the inverse-propagation and design-study workload): the CALLS are sharded
+        across the ranks, results all-gathered -- one small collective for the whole batch."""
+        import torch
+        import torch.distributed as dist
+        us = np.asarray(us, dtype=np.float64)
+        k = us.shape[0]
+        lo, hi = self.shard(k)
+        per = (k + self.world - 1) // self.world
+        mine = torch.zeros((per, 2), dtype=torch.float64)
+        for i in range(lo, hi):
+            mine[i - lo, 0], mine[i - lo, 1] = self.propagate_GA(us[i], Sigmas[i])
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(gathered, mine.to(self.device) if dist.get_backend(self.group) == "nccl" else mine, group=self.group)
+        full = torch.cat([g.cpu() for g in gathered], dim=0).numpy()[:k]
+        return full[:, 0], full[:, 1]
+
+
 # ---------------------------------------------------------------------------------------------------
 # bench.py --gpus N (N > 1): strong scaling of fit + estimate_many at config C4
 # ---------------------------------------------------------------------------------------------------

@@ -38,6 +38,19 @@ def main():
         e2 = max(np.abs(mean - om).max(), np.abs(var - ov).max())
         print("sharded vs single-GPU: %.3e   sharded vs oracle: %.3e" % (e1, e2))
         ok = e1 < 1e-10 and np.allclose(mean, om, rtol=1e-6, atol=1e-9) and np.allclose(var, ov, rtol=1e-6, atol=2e-9)
+    # propagation on the replicated factor: calls sharded over the ranks, every rank gets every result
+    us = np.array([[5.0] * d, [4.0] * d, [6.5] * d, x[3]])
+    Ss = [0.01 * np.eye(d)] * 4
+    pm, pv = gp.propagate_many(us, Ss)
+    if rank == 0:
+        up = sk.UncertaintyPropagationApprox(ref)
+        og_ = orc.OracleGP(x, t, theta)
+        for i in range(4):
+            want = up.propagate_GA(us[i], Ss[i])
+            owant = orc.approx_propagate(og_, us[i], Ss[i])
+            ok = ok and abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9
+            ok = ok and abs(pm[i] - owant[0]) < 1e-8 and abs(pv[i] - owant[1]) < 2e-8
+        print("sharded propagate_many vs single-GPU and oracle:", ok)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     gp.close()

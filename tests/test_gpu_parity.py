@@ -636,3 +636,25 @@ def test_spgp_split_k_path():
     want_var = 2.01 - (solve_triangular(Lm, Ks.T, lower=True) ** 2).sum(0) + (solve_triangular(Lb, Ks.T, lower=True) ** 2).sum(0)
     np.testing.assert_allclose(mu, want_mu, rtol=0, atol=2e-5)
     np.testing.assert_allclose(var, want_var, rtol=0, atol=2e-6)
+
+
+def test_approx_propagation_solve_path_equals_kinv_path():
+    """The first new-u propagations after a fit are served by two triangular solves on the right-hand-side block
+    (no K^-1); once K^-1 exists the one-pass kernel takes over.  Both must give the reference's numbers."""
+    g = load_golden("n256_d8")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    up = sk.UncertaintyPropagationApprox(gp)
+    u0, S0 = g["u0"], g["Sigma0"]
+    u1 = u0 + 0.37
+    a0 = up.propagate_GA(u0, S0)                 # triangular-solve path
+    a1 = up.propagate_GA(u1, S0)
+    d0 = [up._get_variance_dv_h(u0, h) for h in range(len(u0))]
+    _ = gp.Kinv                                  # materialises K^-1 on the device
+    b1 = up.propagate_GA(u1, S0)                 # K^-1 pass
+    b0 = up.propagate_GA(u0, S0)
+    e0 = [up._get_variance_dv_h(u0, h) for h in range(len(u0))]
+    v = np.exp(g["theta"][0])
+    assert a0 == pytest.approx(b0, abs=1e-10 * v) and a1 == pytest.approx(b1, abs=1e-10 * v)
+    assert d0 == pytest.approx(e0, abs=1e-9 * v)
+    assert a0[0] == pytest.approx(float(g["approx_u0_S0"][0]), abs=1e-9)
+    assert a0[1] == pytest.approx(float(g["approx_u0_S0"][1]), abs=1e-8 * v)
