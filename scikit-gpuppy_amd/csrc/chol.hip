@@ -848,6 +848,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     static const int worker_mode = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;   // opt-in: measured slower overall
     unsigned long long *wf = (lw && lw->stream && lw->flags && worker_mode && !(prof && prof->level >= 2)) ? lw->flags : nullptr;
     unsigned long long *wf_chain = (worker_mode == 2) ? nullptr : wf;   // experiment: 2 = worker resident but idle, ordinary leaves
+    static const int merged_update = getenv("GPX_CHOL_MERGED") ? atoi(getenv("GPX_CHOL_MERGED")) : 0;   // 1: narrow update + bulk as one trapezoid launch (measured: no gain)
     auto run = [&]() -> int {
         if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
         // Per outer panel p the main stream runs, in order:
@@ -886,11 +887,18 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
                 GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
+                if (s_bulk == s && merged_update) {
+                    // ONE launch for the rest of panel p+1's columns AND the bulk: a trapezoid whose first B2 - B1 tile
+                    // columns are full (no wave-quantisation tail of a separate 1.75-wave narrow update, no launch boundary)
+                    GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE,
+                                           (nblk - B1) * TILE, K, -1.0, 1.0, 1, s, prof));
+                } else {
                 GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                        K, -1.0, 1.0, 0, s, prof));
                 if (s_bulk != s) GPX_HIP(hipStreamWaitEvent(s_bulk, ev_next[p], 0));
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                        (nblk - B2) * TILE, K, -1.0, 1.0, 1, s_bulk, prof));
+                }
                 if (s_bulk != s) {
                     GPX_HIP(hipEventRecord(ev_bulk[p], s_bulk));
                     GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));

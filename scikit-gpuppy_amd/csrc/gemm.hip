@@ -49,7 +49,7 @@ __device__ __forceinline__ void gpx_acc_fence(v4d &a0, v4d &a1, v4d &a2, v4d &a3
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 template <int WM, int WN, bool LOWER>
 __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
-                                                            double *C, long ldc, int K, double alpha, double beta)
+                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off)
 {
     constexpr bool BIG = (WM * WN > 16);          // 32 accumulators: AGPR-pinned inline-asm MFMA path
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
@@ -71,12 +71,15 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
         if (LOWER) {
-            // 1-D grid over the lower-triangular tiles only (row-major within the triangle), so every XCD chunk
-            // carries the same number of tiles: lid -> (by, bx) with by(by+1)/2 <= lid < (by+1)(by+2)/2
-            by = (int)((sqrt(8.0 * (double)lid + 1.0) - 1.0) * 0.5);
-            while (by * (by + 1) / 2 > lid) --by;
-            while ((by + 1) * (by + 2) / 2 <= lid) ++by;
-            bx = lid - by * (by + 1) / 2;
+            // 1-D grid over the needed tiles only (row-major), so every XCD chunk carries the same number of tiles.
+            // Row by holds the tiles bx <= by + tri_off: tri_off = 0 is the lower triangle of a square C; tri_off > 0 a
+            // trapezoid whose first tri_off tile columns are full (the Cholesky's trailing update including the next
+            // panel's columns).  lid -> (by, bx) with S(by) <= lid < S(by + 1),  S(b) = b (b + 1) / 2 + tri_off b
+            const double o2 = 2.0 * (double)tri_off + 1.0;
+            by = (int)((sqrt(o2 * o2 + 8.0 * (double)lid) - o2) * 0.5);
+            while (by * (by + 1) / 2 + tri_off * by > lid) --by;
+            while ((by + 1) * (by + 2) / 2 + tri_off * (by + 1) <= lid) ++by;
+            bx = lid - (by * (by + 1) / 2 + tri_off * by);
         } else {
             // XCD-aware order: contiguous chunk of the logical tile order per XCD, walked in groups of GM row tiles
             constexpr int GM = 8;
@@ -313,11 +316,13 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: alpha must be non-zero");
         return GPX_ERR_BAD_ARG;
     }
-    if (lower_only && M != N) {
-        gpx_set_error("launch_gemm_nt: lower_only needs a square C");
+    if (lower_only && N < M) {
+        gpx_set_error("launch_gemm_nt: lower_only needs N >= M (square C, or a trapezoid with N - M full columns on the left)");
         return GPX_ERR_BAD_ARG;
     }
-    const double tiles = lower_only ? 0.5 * (double)(M / TILE) * (double)(M / TILE + 1) : (double)(M / TILE) * (double)(N / TILE);
+    const int64_t trap = lower_only ? N - M : 0;   // full columns left of the triangle
+    const double tiles = lower_only ? 0.5 * (double)(M / TILE) * (double)(M / TILE + 1) + (double)(trap / TILE) * (double)(M / TILE)
+                                    : (double)(M / TILE) * (double)(N / TILE);
     // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2
     ProfScope ps(prof, s, tiles >= SMALL_GRID_TILES ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K,
                  tiles >= SMALL_GRID_TILES ? 1 : 2);
@@ -329,13 +334,13 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
 #define GPX_LAUNCH(WM_, WN_)                                                                                          \
     do {                                                                                                              \
         dim3 grid((unsigned)(N / (32 * WN_)), (unsigned)(M / (32 * WM_)));                                            \
-        const unsigned nt_ = (unsigned)(M / (32 * WM_));                                                              \
+        const unsigned nt_ = (unsigned)(M / (32 * WM_)), off_ = (unsigned)(trap / (32 * WN_));                        \
         if (lower_only)                                                                                               \
-            hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta);                                                       \
+            hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2 + off_ * nt_), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
+                               (long)ldc, (int)K, alpha, beta, (int)off_);                                            \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta);                                                       \
+                               (long)ldc, (int)K, alpha, beta, 0);                                                    \
     } while (0)
     static const int big_mode = getenv("GPX_GEMM_BIG") ? atoi(getenv("GPX_GEMM_BIG")) : 0;
     if (big_mode == 3 && !lower_only) GPX_LAUNCH(2, 4);          // experiments: force a tile shape

@@ -658,3 +658,28 @@ def test_approx_propagation_solve_path_equals_kinv_path():
     assert d0 == pytest.approx(e0, abs=1e-9 * v)
     assert a0[0] == pytest.approx(float(g["approx_u0_S0"][0]), abs=1e-9)
     assert a0[1] == pytest.approx(float(g["approx_u0_S0"][1]), abs=1e-8 * v)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 384, 48), (384, 1408, 64), (2048, 3072, 32)])
+def test_gemm_nt_trapezoid(M, N, K):
+    """lower_only with N > M: the first N - M columns are full, the remaining square is lower-triangular by 128-tiles
+    (the Cholesky's merged trailing update); tiles above that staircase must stay untouched."""
+    rng = np.random.RandomState(M + N + K)
+    A, B, C0 = rng.randn(M, K), rng.randn(N, K), rng.randn(M, N)
+    a, b, c = _dev(A), _dev(B), _dev(C0)
+    _gpx.check(_gpx.lib.gpx_dev_gemm_nt(_p(a), K, _p(b), K, _p(c), N, M, N, K, -1.0, 1.0, 1, None), "gemm")
+    torch.cuda.synchronize()
+    got = c.cpu().numpy()
+    want = C0 - A.dot(B.T)
+    off = N - M
+    for bi in range(M // 128):
+        r = slice(128 * bi, 128 * bi + 128)
+        for bj in range(N // 128):
+            cs = slice(128 * bj, 128 * bj + 128)
+            if 128 * bj < off + 128 * bi:          # strictly inside the trapezoid
+                np.testing.assert_allclose(got[r, cs], want[r, cs], rtol=1e-13, atol=1e-12)
+            elif 128 * bj > off + 128 * bi:        # above the staircase: untouched
+                np.testing.assert_array_equal(got[r, cs], C0[r, cs])
+            else:                                    # staircase tile: at least its lower triangle is updated
+                il = np.tril_indices(128)
+                np.testing.assert_allclose(got[r, cs][il], want[r, cs][il], rtol=1e-13, atol=1e-12)
