@@ -686,13 +686,21 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
     const int64_t npad = nblk * TILE;
     GPX_TRY(launch_set_identity(Z, npad, npad, s));
     GPX_TRY(trtri_upper_rec(Z, npad, L, ld, Dinv, 0, nblk, s, prof));
-    const int64_t SB = 8;
-    for (int64_t s0 = 0; s0 < nblk; s0 += SB) {
-        const int64_t s1 = std::min<int64_t>(s0 + SB, nblk);
-        const double *A = Z + (s0 * TILE) * npad + s0 * TILE;    // rows of the strip, k from the strip's first row
-        const double *B = Z + s0 * TILE;                          // rows 0..s1, same k range
-        GPX_TRY(launch_gemm_nt(A, npad, B, npad, Kinv + (s0 * TILE) * npad, npad, (s1 - s0) * TILE, s1 * TILE,
-                               npad - s0 * TILE, 1.0, 0.0, 0, s, prof));
+    // ONE lower-only launch whose tile (by, bx) contracts over k >= 128 by only (Z is upper triangular): N^3/3 flop with
+    // tiles of length 128 .. N dealt longest-first to whichever workgroup slot frees up (row strips of 1024 with a common
+    // k range per strip ran at 49 TFLOP/s: the first strips have few tiles, the last ones short k)
+    static const int strips = getenv("GPX_KINV_STRIPS") ? atoi(getenv("GPX_KINV_STRIPS")) : 0;
+    if (!strips) {
+        GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 0, 1));
+    } else {
+        const int64_t SB = 8;
+        for (int64_t s0 = 0; s0 < nblk; s0 += SB) {
+            const int64_t s1 = std::min<int64_t>(s0 + SB, nblk);
+            const double *A = Z + (s0 * TILE) * npad + s0 * TILE;    // rows of the strip, k from the strip's first row
+            const double *B = Z + s0 * TILE;                          // rows 0..s1, same k range
+            GPX_TRY(launch_gemm_nt(A, npad, B, npad, Kinv + (s0 * TILE) * npad, npad, (s1 - s0) * TILE, s1 * TILE,
+                                   npad - s0 * TILE, 1.0, 0.0, 0, s, prof));
+        }
     }
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }

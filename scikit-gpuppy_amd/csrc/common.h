@@ -116,7 +116,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
 int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
-                   hipStream_t s, Profiler *prof, int big_tiles = 0);
+                   hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0);
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof);
 

@@ -49,7 +49,7 @@ __device__ __forceinline__ void gpx_acc_fence(v4d &a0, v4d &a1, v4d &a2, v4d &a3
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 template <int WM, int WN, bool LOWER>
 __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
-                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off)
+                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim)
 {
     constexpr bool BIG = (WM * WN > 16);          // 32 accumulators: AGPR-pinned inline-asm MFMA path
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         const int nwg = gx * gy;
         const int orig = blockIdx.y * gx + blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
+        // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
+        const int lid = (LOWER && ktrim) ? orig : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
         if (LOWER) {
             // 1-D grid over the needed tiles only (row-major), so every XCD chunk carries the same number of tiles.
             // Row by holds the tiles bx <= by + tri_off: tri_off = 0 is the lower triangle of a square C; tri_off > 0 a
@@ -102,8 +103,11 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     // scalar unit) + (32-bit per-lane byte offset inside the tile: a VGPR that never changes) -- no vector arithmetic
     // per stage (fp64 MFMAs do not co-issue with other VALU work: SQ_VALU_MFMA_COEXEC_CYCLES = 0).
     const int drow = lane >> 3;
-    const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda);
-    const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb);
+    // ktrim (lower-only launches): both operands are UPPER triangular in their own index space (operand[i][k] = 0 for
+    // k < i), so tile (by, bx <= by) contracts over k >= by * BTM only -- K^-1 = L^-T L^-1 as one launch
+    const long kstart = (LOWER && ktrim) ? (long)by * BTM : 0;
+    const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda + kstart);
+    const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb + kstart);
     unsigned aoff[(BTM / 8 + 3) / 4], boff[(BTN / 8 + 3) / 4];
 #pragma unroll
     for (int u = 0; u < (BTM / 8 + 3) / 4; ++u) {
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
         }                                                                                                           \
     }
 
-    const int nk = K / GEMM_BK;
+    const int nk = (K - (int)kstart) / GEMM_BK;
     constexpr int NDMA = (BTM / 8 + 3) / 4 + (BTN / 8 + 3) / 4;   // LDS-DMA instructions per wave per stage
     GPX_DMA_STAGE(0, 0)
     // C enters through the accumulators: acc0 = (beta/alpha) C, result = alpha (acc0 + A B^T).  The tile's read
@@ -303,7 +307,7 @@ extern "C" int gpx_stamp_read(unsigned long long *out)
 constexpr double SMALL_GRID_TILES = 192.0;
 
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
-                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles)
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles, int ktrim)
 {
     if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
@@ -318,6 +322,10 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     }
     if (lower_only && N < M) {
         gpx_set_error("launch_gemm_nt: lower_only needs N >= M (square C, or a trapezoid with N - M full columns on the left)");
+        return GPX_ERR_BAD_ARG;
+    }
+    if (ktrim && (!lower_only || N != M || K != M)) {
+        gpx_set_error("launch_gemm_nt: ktrim needs a square lower-only launch with K == M");
         return GPX_ERR_BAD_ARG;
     }
     const int64_t trap = lower_only ? N - M : 0;   // full columns left of the triangle
@@ -337,10 +345,10 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         const unsigned nt_ = (unsigned)(M / (32 * WM_)), off_ = (unsigned)(trap / (32 * WN_));                        \
         if (lower_only)                                                                                               \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2 + off_ * nt_), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, (int)off_);                                            \
+                               (long)ldc, (int)K, alpha, beta, (int)off_, ktrim);                                            \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, 0);                                                    \
+                               (long)ldc, (int)K, alpha, beta, 0, 0);                                                    \
     } while (0)
     static const int big_mode = getenv("GPX_GEMM_BIG") ? atoi(getenv("GPX_GEMM_BIG")) : 0;
     if (big_mode == 3 && !lower_only) GPX_LAUNCH(2, 4);          // experiments: force a tile shape
