@@ -683,3 +683,30 @@ def test_gemm_nt_trapezoid(M, N, K):
             else:                                    # staircase tile: at least its lower triangle is updated
                 il = np.tril_indices(128)
                 np.testing.assert_allclose(got[r, cs][il], want[r, cs][il], rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("N,d,M,seed", [(2500, 32, 100, 1), (3000, 1, 257, 2), (5000, 16, 300, 3), (1153, 64, 64, 4), (2049, 2, 1025, 5)])
+def test_against_oracle_sweep_random_theta(N, d, M, seed):
+    """fresh seeded inputs with random hyper-parameters, input dimensions up to GPX_MAX_D = 64, sizes that cross the
+    look-ahead factorisation's panel boundaries (N > 1024) and are not tile multiples."""
+    rng = np.random.RandomState(7000 + seed)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1) / np.sqrt(d)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (M, d))
+    theta = np.concatenate([[rng.uniform(-0.5, 1.0), rng.uniform(-5.0, -3.0)], rng.uniform(-4.5, -2.5, d) - np.log(d) / 2])
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    og = orc.OracleGP(x, t, theta)
+    mean, var = gp.estimate_many(xs)
+    om, ov = og.estimate_many(xs)
+    v = np.exp(theta[0])
+    np.testing.assert_allclose(mean, om, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(var, ov, rtol=1e-6, atol=1e-8 * v)
+    assert gp._dev().logdet() == pytest.approx(og.logdet(), rel=1e-9, abs=1e-6)
+    u = xs[1 % M]
+    S = np.diag(rng.uniform(0.005, 0.05, d))
+    ma, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+    oma, ova = orc.approx_propagate(og, u, S)
+    assert ma == pytest.approx(oma, abs=1e-8) and va == pytest.approx(ova, abs=1e-7 * v)
+    me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
+    ome, ove = orc.exact_propagate(og, u, S)
+    assert me == pytest.approx(ome, abs=1e-8) and ve == pytest.approx(ove, abs=1e-7 * v)
