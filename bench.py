@@ -218,6 +218,15 @@ def run_single(args):
             (args.workload or "c3").upper(), N, d, M), "global_batch": N + M, "parallelism": "1 GPU"},
         "fit_ms": t_fit[0] / args.steps * 1e3,
         "predict_ms": t_pred[0] / args.steps * 1e3,
+        # per-stage view: whole-stage algorithmic flops / stage wall time against the fp64 MFMA peak
+        "stages": {
+            "fit": {"pts_per_s": N * args.steps / t_fit[0], "algorithmic_flops": N ** 3 / 3.0,
+                    "tflops": N ** 3 / 3.0 * args.steps / t_fit[0] / 1e12,
+                    "frac_of_peak": N ** 3 / 3.0 * args.steps / t_fit[0] / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+            "estimate_many": {"pts_per_s": M * args.steps / t_pred[0], "algorithmic_flops": float(N) * N * M,
+                              "tflops": float(N) * N * M * args.steps / t_pred[0] / 1e12,
+                              "frac_of_peak": float(N) * N * M * args.steps / t_pred[0] / 1e12 / FP64_MFMA_PEAK_TFLOPS},
+        },
         "roofline": {
             "kernel": "gemm_nt_f64_kernel (v_mfma_f64_16x16x4_f64)",
             "bound": "mfma",
