@@ -192,7 +192,7 @@ extern "C" int gpx_pool_trim(void)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto &kv : g_pool_free)
-        for (void *q : kv.second) dfree(q);
+        for (void *q : kv.second) (void)hipFree(q);   // cached blocks are no longer in g_pool_live: release them to the driver
     g_pool_free.clear();
     g_pool_cached_bytes = 0;
     return 0;

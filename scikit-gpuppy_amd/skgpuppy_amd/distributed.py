@@ -350,6 +350,9 @@ def bench_main(args):
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("GPX_BENCH_WATCHDOG"):       # diagnostic: Python stack of a stuck run after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GPX_BENCH_WATCHDOG"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -396,6 +399,32 @@ def bench_main(args):
     elapsed = torch.tensor([time.perf_counter() - t0, t_fit, t_pred], dtype=torch.float64, device=dev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     el, tf, tp = [float(v) for v in elapsed.cpu()]
+
+    # Reference for the strong-scaling numbers, outside the timed region: the SAME workload on ONE GPU (rank 0, single-GPU
+    # library path), so that the line carries its own 1-GPU baseline (the N=1 bench line is the C3 headline, another workload)
+    one_gpu = None
+    if (world > 1 or os.environ.get("GPX_BENCH_FORCE_1GPU_REF")) and rank == 0 and not os.environ.get("GPX_BENCH_SKIP_1GPU_REF"):
+        xd = torch.as_tensor(x).to(dev)
+        td = torch.as_tensor(t - np.mean(t)).to(dev)
+        xq = torch.as_tensor(xs).to(dev)
+        mq = torch.empty(M, dtype=torch.float64, device=dev)
+        vq = torch.empty(M, dtype=torch.float64, device=dev)
+        vp = lambda tt: ctypes.c_void_p(tt.data_ptr())  # noqa: E731
+        th = np.ascontiguousarray(theta, dtype=np.float64)
+        best = None
+        for _rep in range(2):           # first repetition warms this path's allocations
+            h1 = ctypes.c_void_p()
+            a = time.perf_counter()
+            _gpx.check(_gpx.lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h1)), "gpx_fit (1-GPU reference)")
+            b = time.perf_counter()
+            _gpx.check(_gpx.lib.gpx_predict(h1, vp(xq), M, vp(mq), vp(vq)), "gpx_predict (1-GPU reference)")
+            c = time.perf_counter()
+            _gpx.lib.gpx_free(h1)
+            best = (c - a, b - a, c - b)
+        _gpx.lib.gpx_pool_trim()
+        one_gpu = {"ms_per_step": best[0] * 1e3, "fit_ms": best[1] * 1e3, "predict_ms": best[2] * 1e3,
+                   "value": (N + M) / best[0], "note": "same workload, one GPU, single-GPU library path, timed on rank 0 after the timed region"}
+    dist.barrier()
     if rank == 0:
         flops = N ** 3 / 3.0 + float(N) * N * M
         line = (json.dumps({
@@ -416,6 +445,7 @@ def bench_main(args):
                        "global_batch": N + M, "parallelism": "panel-sharded x%d" % world},
             "fit_ms": tf / args.steps * 1e3,
             "predict_ms": tp / args.steps * 1e3,
+            "one_gpu_same_workload": one_gpu,
             "roofline": {"kernel": "gemm_nt_f64_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                          "achieved": flops * args.steps / el / 1e12 / world, "peak": bench_mod.FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops * args.steps / el / 1e12 / world / bench_mod.FP64_MFMA_PEAK_TFLOPS,

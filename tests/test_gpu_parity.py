@@ -710,3 +710,19 @@ def test_against_oracle_sweep_random_theta(N, d, M, seed):
     me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
     ome, ove = orc.exact_propagate(og, u, S)
     assert me == pytest.approx(ome, abs=1e-8) and ve == pytest.approx(ove, abs=1e-7 * v)
+
+
+def test_pool_trim_releases_cached_buffers():
+    """gpx_free parks device buffers in the library's cache; gpx_pool_trim hands them back to the driver (it is also the
+    out-of-memory retry path of every allocation) and the library keeps working afterwards."""
+    g = load_golden("n256_d8")
+    gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    m0, _ = gp.estimate_many(g["xs"][:5])
+    _ = gp.Kinv                                                          # a few MB more in the cache
+    gp._dev().close()
+    cached = torch.cuda.mem_get_info()[0]
+    assert _gpx.lib.gpx_pool_trim() == 0
+    assert torch.cuda.mem_get_info()[0] >= cached + (1 << 20)            # the parked factor / K^-1 / workspaces went back
+    assert _gpx.lib.gpx_pool_trim() == 0                                 # idempotent on an empty cache
+    gp2 = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+    np.testing.assert_array_equal(gp2.estimate_many(g["xs"][:5])[0], m0)
