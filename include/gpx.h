@@ -166,6 +166,8 @@ int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_dev, int64_t
 /* C = alpha * A B^T + beta * C  with A[M,K], B[N,K]; lower_only skips tiles above the diagonal */
 int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream);
+/* (lower_only: only the 128-tiles on/below the diagonal of a square C are computed; with N > M the first N - M columns are
+ * full and the remaining M x M square is lower-triangular by tiles) */
 /* factor one 128x128 diagonal block in place (lower) and write its inverse to dinv[128*128];
  * info_dev: device int, set to 1-based failing column + col_offset on a non-positive pivot */
 int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset, void *stream);
@@ -177,6 +179,7 @@ int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t 
                        int *info_dev, void *stream);
 /* build a handle around an EXISTING factor in HBM (L [npad,npad] with ld == npad, dinv [npad/128,128,128],
  * diag [npad]; the caller keeps ownership and must keep them alive): solves for alpha; predict / propagate as usual.
+ * The strictly-upper 128x128 tiles of L_dev are scratch for the library (the first Approx propagation stores L^T there).
  * Used by the sharded fit, where every rank ends up with the full factor after the panel broadcasts. */
 int gpx_adopt_factor(const double *x, const double *t_centered, int64_t n, int d, const double *theta, double *L_dev,
                      double *dinv_dev, double *diag_dev, double jitter, void *stream, gpx_handle **out);
