@@ -726,3 +726,22 @@ def test_pool_trim_releases_cached_buffers():
     assert _gpx.lib.gpx_pool_trim() == 0                                 # idempotent on an empty cache
     gp2 = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
     np.testing.assert_array_equal(gp2.estimate_many(g["xs"][:5])[0], m0)
+
+
+def test_spgp_ml_fit_like_reference_test_gp_2d():
+    """the reference's test_gp_2D with SPGPCovariance(10) (skgpuppy/tests/tests.py:708-747; it errors on Python 3 inside the
+    reference's analytic SPGP gradient): the default constructor runs the ML fit and the predictor stays within a few
+    sigma of the generating surface."""
+    g = load_golden("kat1_grid")
+    x, t = g["x"], g["ml_t_raw"]
+    np.random.seed(3)
+    cov = sk.SPGPCovariance(10)
+    start = cov.get_theta(x, t - t.mean())
+    nll0 = cov._negativeloglikelihood(x, t - t.mean(), start)
+    gp = sk.GaussianProcess(x, t, sk.SPGPCovariance(10))          # L-BFGS-B on Snelson's likelihood
+    nll1 = gp.cov._negativeloglikelihood(x, gp.t, gp.theta_min)
+    assert np.isfinite(nll1) and nll1 <= nll0 + 1e-6
+    mu, var = gp.estimate_many(x)
+    assert np.all(var > 0)
+    resid = np.abs(mu - t)
+    assert np.mean(resid < 5 * np.sqrt(var)) > 0.9
