@@ -188,12 +188,56 @@ void dfree(void *p)
     g_pool_live.erase(it);
 }
 
+// Streams are cached like device buffers: creating and (synchronously) destroying the two or three streams of a handle
+// costs more than a small fit (0.8 ms per gpx_free measured with hipStreamDestroy / hipFree in it).
+namespace {
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_cache;   // (device, high priority) -> idle streams
+}
+
+hipStream_t stream_acquire(int high_priority)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_stream_cache.find({dev, high_priority});
+        if (it != g_stream_cache.end() && !it->second.empty()) {
+            hipStream_t s = it->second.back();
+            it->second.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (high_priority) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
+    } else
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+
+// the stream must be idle (callers synchronise it first)
+void stream_release(hipStream_t s, int high_priority)
+{
+    if (!s) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipStreamDestroy(s); return; }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_stream_cache[{dev, high_priority}].push_back(s);
+}
+
 extern "C" int gpx_pool_trim(void)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     for (auto &kv : g_pool_free)
         for (void *q : kv.second) (void)hipFree(q);   // cached blocks are no longer in g_pool_live: release them to the driver
     g_pool_free.clear();
+    for (auto &kv : g_stream_cache)
+        for (hipStream_t st : kv.second) (void)hipStreamDestroy(st);
+    g_stream_cache.clear();
     g_pool_cached_bytes = 0;
     return 0;
 }
@@ -320,12 +364,16 @@ extern "C" void gpx_free(gpx_handle *h)
     double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV, h->DinvT};
     for (double *p : bufs)
         if (p) dfree(p);
-    if (h->info_dev) (void)hipFree(h->info_dev);
-    if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); (void)hipStreamDestroy(h->s_pan); }
+    if (h->info_dev) dfree(h->info_dev);
+    if (h->s_pan) {
+        (void)hipStreamSynchronize(h->s_pan);
+        if (h->masked_streams) (void)hipStreamDestroy(h->s_pan);
+        else stream_release(h->s_pan, 1);
+    }
     if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
-    if (h->leaf.stream) { (void)hipStreamSynchronize(h->leaf.stream); (void)hipStreamDestroy(h->leaf.stream); }
-    if (h->leaf.flags) (void)hipFree(h->leaf.flags);
-    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->leaf.stream) { (void)hipStreamSynchronize(h->leaf.stream); stream_release(h->leaf.stream, 0); }
+    if (h->leaf.flags) dfree(h->leaf.flags);
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, 0); }
     delete h;
 }
 
@@ -358,7 +406,7 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
     h->nblk = h->npad / TILE;
     if (stream) h->stream = (hipStream_t)stream;
     else {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
+        if (!(h->stream = stream_acquire(0))) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
         h->own_stream = true;
     }
     hipStream_t s = h->stream;
@@ -381,6 +429,7 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
             if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
                 masked = true;
+                h->masked_streams = true;
             }
             else {
                 (void)hipGetLastError();
@@ -389,18 +438,13 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
             }
         }
         if (!masked) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
-            // persistent leaf worker of the look-ahead factorisation: its own high-priority stream + hand-off words
-            static const int wprio = getenv("GPX_LEAF_WORKER_PRIO") ? atoi(getenv("GPX_LEAF_WORKER_PRIO")) : 0;   // 0 = lowest, 1 = highest
-            if (h->s_pan && hipStreamCreateWithPriority(&h->leaf.stream, hipStreamNonBlocking, wprio ? greatest : least) == hipSuccess) {
-                if (hipMalloc((void **)&h->leaf.flags, 4 * sizeof(unsigned long long)) != hipSuccess) {
-                    (void)hipGetLastError();
-                    h->leaf.flags = nullptr;
-                }
-            } else
-                h->leaf.stream = nullptr;
+            h->s_pan = stream_acquire(1);
+            // persistent leaf worker of the look-ahead factorisation (opt-in): its own stream + hand-off words
+            static const int worker_on = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;
+            if (h->s_pan && worker_on && (h->leaf.stream = stream_acquire(0))) {
+                double *fl = nullptr;
+                if (dalloc(&fl, 4) == 0) h->leaf.flags = reinterpret_cast<unsigned long long *>(fl);
+            }
         }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };
@@ -415,7 +459,11 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
         (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
     h->small_elems = 4096 + h->npad;
-    if (hipMalloc((void **)&h->info_dev, sizeof(int) * (2 + 2 * h->nblk)) != hipSuccess) { gpx_set_error("hipMalloc info failed"); return fail(GPX_ERR_HIP); }
+    {
+        double *ib = nullptr;
+        if ((rc = dalloc(&ib, h->nblk + 2))) return fail(rc);   // (2 + 2 nblk) ints
+        h->info_dev = reinterpret_cast<int *>(ib);
+    }
     if (hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), h->stream) != hipSuccess) { gpx_set_error("hipMemset info failed"); return fail(GPX_ERR_HIP); }
 
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
@@ -476,7 +524,7 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
     h->nblk = h->npad / TILE;
     if (stream) h->stream = (hipStream_t)stream;
     else {
-        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
+        if (!(h->stream = stream_acquire(0))) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
         h->own_stream = true;
     }
     hipStream_t s = h->stream;
@@ -499,6 +547,7 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
             if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
                 hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
                 masked = true;
+                h->masked_streams = true;
             }
             else {
                 (void)hipGetLastError();
@@ -507,9 +556,7 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
             }
         }
         if (!masked) {
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            if (hipStreamCreateWithPriority(&h->s_pan, hipStreamNonBlocking, greatest) != hipSuccess) h->s_pan = nullptr;
+            h->s_pan = stream_acquire(1);
         }
     }
     auto fail = [&](int code) { gpx_free(h); return code; };
@@ -523,7 +570,11 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
         (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
     h->small_elems = 4096 + h->npad;
-    if (hipMalloc((void **)&h->info_dev, sizeof(int) * (2 + 2 * h->nblk)) != hipSuccess) { gpx_set_error("hipMalloc info failed"); return fail(GPX_ERR_HIP); }
+    {
+        double *ib = nullptr;
+        if ((rc = dalloc(&ib, h->nblk + 2))) return fail(rc);   // (2 + 2 nblk) ints
+        h->info_dev = reinterpret_cast<int *>(ib);
+    }
     if (hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), h->stream) != hipSuccess) { gpx_set_error("hipMemset info failed"); return fail(GPX_ERR_HIP); }
 
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)

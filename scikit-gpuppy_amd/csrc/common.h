@@ -77,6 +77,7 @@ struct gpx_handle {
     hipStream_t s_pan = nullptr;   // side stream for the latency-bound diagonal chain (CU-masked: a few reserved CUs)
     hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
     LeafWorker leaf;               // persistent leaf worker of the factorisation (stream + hand-off words)
+    bool masked_streams = false;   // s_pan / s_bulk were created with CU masks (not cacheable)
 
     double *x = nullptr;        // [n, d] raw inputs
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
@@ -145,9 +146,11 @@ int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad,
 int launch_set_identity(double *Z, int64_t ld, int64_t n, hipStream_t s);
 int launch_symmetrize_lower(double *A, int64_t ld, int64_t n, hipStream_t s);
 
-// caching device allocator (api.hip)
+// caching device allocator and stream cache (api.hip)
 int dalloc(double **p, int64_t elems);
 void dfree(void *p);
+hipStream_t stream_acquire(int high_priority);
+void stream_release(hipStream_t s, int high_priority);
 
 // propagate.hip
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);

@@ -176,13 +176,13 @@ extern "C" void gpx_spgp_free(gpx_spgp *h)
     void *bufs[] = {h->xw, h->xbw, h->sw, h->t, h->Knm, h->Z, h->Wt, h->LM, h->DinvM, h->diagM, h->LB, h->DinvB, h->diagB, h->lam,
                     h->ilam, h->va, h->vb, h->vc, h->ma, h->mb, h->mzero, h->beta, h->mscr, h->outd};
     for (void *p : bufs) dfree(p);
-    if (h->info) (void)hipFree(h->info);
+    if (h->info) dfree(h->info);
     for (int c = 1; c < gpx_spgp::SPLIT; ++c)
-        if (h->split_stream[c]) { (void)hipStreamSynchronize(h->split_stream[c]); (void)hipStreamDestroy(h->split_stream[c]); }
+        if (h->split_stream[c]) { (void)hipStreamSynchronize(h->split_stream[c]); stream_release(h->split_stream[c], 0); }
     for (int c = 0; c <= gpx_spgp::SPLIT; ++c)
         if (h->split_ev[c]) (void)hipEventDestroy(h->split_ev[c]);
     dfree(h->split_buf);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream) stream_release(h->stream, 0);
     delete h;
 }
 
@@ -220,7 +220,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     const int d = h->d;
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(exp(theta[2 + k]));
-    GPX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (!(h->stream = stream_acquire(0))) { gpx_set_error("stream creation failed"); return GPX_ERR_HIP; }
     hipStream_t s = h->stream;
     const int64_t tt = h->mblk * (int64_t)TILE * TILE;
     GPX_TRY(dalloc(&h->xw, np * d)); GPX_TRY(dalloc(&h->xbw, mp * d)); GPX_TRY(dalloc(&h->sw, d)); GPX_TRY(dalloc(&h->t, np));
@@ -230,11 +230,16 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(dalloc(&h->lam, np)); GPX_TRY(dalloc(&h->ilam, np)); GPX_TRY(dalloc(&h->va, np)); GPX_TRY(dalloc(&h->vb, np)); GPX_TRY(dalloc(&h->vc, np));
     GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
     GPX_TRY(dalloc(&h->outd, 8));
-    GPX_HIP(hipMalloc((void **)&h->info, sizeof(int)));
+    {
+        double *ib = nullptr;
+        GPX_TRY(dalloc(&ib, 1));
+        h->info = reinterpret_cast<int *>(ib);
+    }
     if (np >= 16384) {   // split-K machinery of spgp_wtw
         GPX_TRY(dalloc(&h->split_buf, (int64_t)(gpx_spgp::SPLIT - 1) * mp * mp));
         GPX_HIP(hipMemsetAsync(h->split_buf, 0, sizeof(double) * (gpx_spgp::SPLIT - 1) * mp * mp, s));
-        for (int c = 1; c < gpx_spgp::SPLIT; ++c) GPX_HIP(hipStreamCreateWithFlags(&h->split_stream[c], hipStreamNonBlocking));
+        for (int c = 1; c < gpx_spgp::SPLIT; ++c)
+            if (!(h->split_stream[c] = stream_acquire(0))) { gpx_set_error("stream creation failed"); return GPX_ERR_HIP; }
         for (int c = 0; c <= gpx_spgp::SPLIT; ++c) GPX_HIP(hipEventCreateWithFlags(&h->split_ev[c], hipEventDisableTiming));
     }
     // raw inputs are staged through Z / LB (both overwritten below)
