@@ -745,3 +745,30 @@ def test_spgp_ml_fit_like_reference_test_gp_2d():
     assert np.all(var > 0)
     resid = np.abs(mu - t)
     assert np.mean(resid < 5 * np.sqrt(var)) > 0.9
+
+
+def test_two_threads_two_handles():
+    """SURVEY.md 8b threading contract: a handle is single-owner, distinct handles may be driven from distinct threads
+    (ctypes releases the GIL; the allocator and stream caches are shared)."""
+    import threading
+    g = load_golden("n1000_d4")
+    ref = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy()).estimate_many(g["xs"])
+    errs = []
+
+    def work(seed):
+        try:
+            for _ in range(6):
+                gp = sk.GaussianProcess(g["x"], g["t_raw"], sk.GaussianCovariance(), g["theta"].copy())
+                m, v = gp.estimate_many(g["xs"])
+                np.testing.assert_array_equal(m, ref[0])
+                np.testing.assert_array_equal(v, ref[1])
+                up = sk.UncertaintyPropagationApprox(gp).propagate_GA(g["u0"], g["Sigma0"])
+                assert up[0] == pytest.approx(float(g["approx_u0_S0"][0]), abs=1e-9)
+                gp._dev().close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
