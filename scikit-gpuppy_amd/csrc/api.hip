@@ -388,12 +388,46 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     return 0;
 }
 
-extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
-                       gpx_handle **out)
+// One constructor for both kinds of handle: ext == nullptr factors K here (gpx_fit), otherwise the handle wraps a factor
+// that already sits in HBM (gpx_adopt_factor) and only alpha is solved for.
+struct ExternalFactor { double *L, *Dinv, *diag; double jitter; };
+
+static void setup_lookahead_streams(gpx_handle *h)
 {
-    if (out) *out = nullptr;
-    GPX_TRY(require_device());
-    if (!x || !t_centered || !out || n < 1) { gpx_set_error("gpx_fit: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
+    // The diagonal chain of the next panel runs on a second, high-priority stream underneath the main stream's work.
+    // GPX_RESERVED_CUS > 0 instead reserves CUs for it with CU masks (measured slower on ROCm 7.2: excluding one CU per
+    // XCD costs the bulk 12 %, tools/probe_cumask.py), GPX_LEAF_WORKER = 1 adds the persistent leaf worker (opt-in).
+    int ncu = 0;
+    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
+    int reserve = 0;
+    if (const char *e = getenv("GPX_RESERVED_CUS")) reserve = atoi(e);
+    if (ncu >= 64 && reserve > 0 && reserve < ncu / 2) {
+        const int words = (ncu + 31) / 32;
+        std::vector<uint32_t> m_side(words, 0u), m_bulk(words, 0u);
+        for (int c = 0; c < ncu; ++c) {
+            if (c < reserve) m_side[c >> 5] |= 1u << (c & 31);
+            else m_bulk[c >> 5] |= 1u << (c & 31);
+        }
+        if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
+            hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
+            h->masked_streams = true;
+            return;
+        }
+        (void)hipGetLastError();
+        if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
+        h->s_bulk = nullptr;
+    }
+    h->s_pan = stream_acquire(1);
+    static const int worker_on = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;
+    if (h->s_pan && worker_on && (h->leaf.stream = stream_acquire(0))) {
+        double *fl = nullptr;
+        if (dalloc(&fl, 4) == 0) h->leaf.flags = reinterpret_cast<unsigned long long *>(fl);
+    }
+}
+
+static int make_handle(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
+                       const ExternalFactor *ext, gpx_handle **out)
+{
     gpx_handle *h = new (std::nothrow) gpx_handle();
     if (!h) { gpx_set_error("out of host memory"); return GPX_ERR_HIP; }
     h->device = g_device;
@@ -410,86 +444,58 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
         h->own_stream = true;
     }
     hipStream_t s = h->stream;
-    {
-        // Look-ahead streams.  The diagonal chain of the next panel must not fight the MFMA-saturating bulk
-        // update for issue slots (it runs 3-4x slower when it does), so a few CUs are reserved for it with CU
-        // masks: GPX_RESERVED_CUS (spread over the XCDs; default 0 = use a high-priority stream instead) for the side stream, the rest for the bulk.
-        int ncu = 0;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
-        int reserve = 0;   // CU masks measured slower on ROCm 7.2 (the unmasked stream's dispatches slow down): off by default
-        if (const char *e = getenv("GPX_RESERVED_CUS")) reserve = atoi(e);
-        bool masked = false;
-        if (ncu >= 64 && reserve > 0 && reserve < ncu / 2) {
-            const int words = (ncu + 31) / 32;
-            std::vector<uint32_t> m_side(words, 0u), m_bulk(words, 0u);
-            for (int c = 0; c < ncu; ++c) {
-                if (c < reserve) m_side[c >> 5] |= 1u << (c & 31);
-                else m_bulk[c >> 5] |= 1u << (c & 31);
-            }
-            if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
-                masked = true;
-                h->masked_streams = true;
-            }
-            else {
-                (void)hipGetLastError();
-                if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
-                h->s_bulk = nullptr;
-            }
-        }
-        if (!masked) {
-            h->s_pan = stream_acquire(1);
-            // persistent leaf worker of the look-ahead factorisation (opt-in): its own stream + hand-off words
-            static const int worker_on = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;
-            if (h->s_pan && worker_on && (h->leaf.stream = stream_acquire(0))) {
-                double *fl = nullptr;
-                if (dalloc(&fl, 4) == 0) h->leaf.flags = reinterpret_cast<unsigned long long *>(fl);
-            }
-        }
-    }
+    if (!ext) setup_lookahead_streams(h);
     auto fail = [&](int code) { gpx_free(h); return code; };
-    if (const char *pe = getenv("GPX_PROFILE")) h->prof.level = atoi(pe);   // covers the kernels of gpx_fit itself
+    if (const char *pe = getenv("GPX_PROFILE")) h->prof.level = atoi(pe);   // covers the kernels of the constructor itself
 
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
     if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
-        (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->L, h->npad * h->npad)) ||
-        (rc = dalloc(&h->Dinv, h->nblk * (int64_t)TILE * TILE)) || (rc = dalloc(&h->diagL, h->npad)) ||
-        (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) || (rc = dalloc(&h->alpha, h->npad)) ||
-        (rc = dalloc(&h->small, 4096 + h->npad)))
+        (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) ||
+        (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
     h->small_elems = 4096 + h->npad;
+    if (ext) {
+        h->external_factor = true;
+        h->L = ext->L;
+        h->Dinv = ext->Dinv;
+        h->diagL = ext->diag;
+        h->jitter = ext->jitter;
+    } else if ((rc = dalloc(&h->L, h->npad * h->npad)) || (rc = dalloc(&h->Dinv, h->nblk * (int64_t)TILE * TILE)) ||
+               (rc = dalloc(&h->diagL, h->npad)))
+        return fail(rc);
     {
         double *ib = nullptr;
         if ((rc = dalloc(&ib, h->nblk + 2))) return fail(rc);   // (2 + 2 nblk) ints
         h->info_dev = reinterpret_cast<int *>(ib);
     }
-    if (hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), h->stream) != hipSuccess) { gpx_set_error("hipMemset info failed"); return fail(GPX_ERR_HIP); }
-
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
+    FIT_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), s));
     FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
     FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
     FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
     FIT_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * h->npad, s));
     FIT_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
-    FIT_HIP(hipStreamSynchronize(s));   // sw / h->w are stack/handle memory: make the copies complete before returning paths
+    FIT_HIP(hipStreamSynchronize(s));   // sw is a stack buffer: its copy must be complete before any return path
     if ((rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
 
-    int info = 0;
-    if ((rc = factor_once(h, h->vt, &info))) return fail(rc);
-    if (info > 0) {
-        // reference fallback: cholesky(K + 1e-5 I)   (skgpuppy/Covariance.py:180-185)
-        h->jitter = 1e-5;
-        if ((rc = factor_once(h, h->vt + h->jitter, &info))) return fail(rc);
+    if (!ext) {
+        int info = 0;
+        if ((rc = factor_once(h, h->vt, &info))) return fail(rc);
         if (info > 0) {
-            gpx_set_error("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter", info);
-            return fail(info);
+            // reference fallback: cholesky(K + 1e-5 I)   (skgpuppy/Covariance.py:180-185)
+            h->jitter = 1e-5;
+            if ((rc = factor_once(h, h->vt + h->jitter, &info))) return fail(rc);
+            if (info > 0) {
+                gpx_set_error("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter", info);
+                return fail(info);
+            }
         }
     }
+    // alpha = L^-T (L^-1 t).  The single-launch wavefront solves (trsv.hip) are correct but measured slower than the per-step
+    // kernels on MI355X (hand-off latency on the 128-step critical path): opt-in only.
     static const bool use_wavefront = getenv("GPX_TRSV_WAVEFRONT") && getenv("GPX_TRSV_WAVEFRONT")[0] == '1';
-    // The single-launch wavefront solves (trsv.hip) are correct but measured slower than the per-step kernels on
-    // MI355X (hand-off + reduction latency on the 128-step critical path: 10 ms vs 5.8 ms at N=16384): opt-in only.
-    if (use_wavefront && h->nblk <= 2048) {   // every workgroup must be resident: 256 CUs x 8 small workgroups
+    if (use_wavefront && h->nblk <= 2048) {
         int solve_err = 0;
         if ((rc = trsv_wavefront_pair(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->alpha, h->info_dev + 2, 1, h->info_dev + 1, s, &h->prof))) return fail(rc);
         FIT_HIP(hipMemcpyAsync(&solve_err, h->info_dev + 1, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -505,6 +511,15 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
     return 0;
 }
 
+extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
+                       gpx_handle **out)
+{
+    if (out) *out = nullptr;
+    GPX_TRY(require_device());
+    if (!x || !t_centered || !out || n < 1) { gpx_set_error("gpx_fit: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
+    return make_handle(x, t_centered, n, d, theta, stream, nullptr, out);
+}
+
 extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64_t n, int d, const double *theta,
                                 double *L_dev, double *dinv_dev, double *diag_dev, double jitter, void *stream,
                                 gpx_handle **out)
@@ -512,102 +527,8 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
     if (out) *out = nullptr;
     GPX_TRY(require_device());
     if (!x || !t_centered || !out || n < 1 || !L_dev || !dinv_dev || !diag_dev) { gpx_set_error("gpx_adopt_factor: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
-    gpx_handle *h = new (std::nothrow) gpx_handle();
-    if (!h) { gpx_set_error("out of host memory"); return GPX_ERR_HIP; }
-    h->device = g_device;
-    int rc = parse_theta(theta, d, &h->v, &h->vt, h->w);
-    if (rc) { delete h; return rc; }
-    memcpy(h->theta, theta, sizeof(double) * (d + 2));
-    h->n = n;
-    h->d = d;
-    h->npad = round_up(n, TILE);
-    h->nblk = h->npad / TILE;
-    if (stream) h->stream = (hipStream_t)stream;
-    else {
-        if (!(h->stream = stream_acquire(0))) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
-        h->own_stream = true;
-    }
-    hipStream_t s = h->stream;
-    {
-        // Look-ahead streams.  The diagonal chain of the next panel must not fight the MFMA-saturating bulk
-        // update for issue slots (it runs 3-4x slower when it does), so a few CUs are reserved for it with CU
-        // masks: GPX_RESERVED_CUS (spread over the XCDs; default 0 = use a high-priority stream instead) for the side stream, the rest for the bulk.
-        int ncu = 0;
-        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
-        int reserve = 0;   // CU masks measured slower on ROCm 7.2 (the unmasked stream's dispatches slow down): off by default
-        if (const char *e = getenv("GPX_RESERVED_CUS")) reserve = atoi(e);
-        bool masked = false;
-        if (ncu >= 64 && reserve > 0 && reserve < ncu / 2) {
-            const int words = (ncu + 31) / 32;
-            std::vector<uint32_t> m_side(words, 0u), m_bulk(words, 0u);
-            for (int c = 0; c < ncu; ++c) {
-                if (c < reserve) m_side[c >> 5] |= 1u << (c & 31);
-                else m_bulk[c >> 5] |= 1u << (c & 31);
-            }
-            if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
-                hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
-                masked = true;
-                h->masked_streams = true;
-            }
-            else {
-                (void)hipGetLastError();
-                if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
-                h->s_bulk = nullptr;
-            }
-        }
-        if (!masked) {
-            h->s_pan = stream_acquire(1);
-        }
-    }
-    auto fail = [&](int code) { gpx_free(h); return code; };
-    if (const char *pe = getenv("GPX_PROFILE")) h->prof.level = atoi(pe);   // covers the kernels of gpx_fit itself
-
-    double sw[GPX_MAX_D];
-    for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
-    if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
-        (rc = dalloc(&h->wdev, d)) ||
-        (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) || (rc = dalloc(&h->alpha, h->npad)) ||
-        (rc = dalloc(&h->small, 4096 + h->npad)))
-        return fail(rc);
-    h->small_elems = 4096 + h->npad;
-    {
-        double *ib = nullptr;
-        if ((rc = dalloc(&ib, h->nblk + 2))) return fail(rc);   // (2 + 2 nblk) ints
-        h->info_dev = reinterpret_cast<int *>(ib);
-    }
-    if (hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), h->stream) != hipSuccess) { gpx_set_error("hipMemset info failed"); return fail(GPX_ERR_HIP); }
-
-#define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
-    FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
-    FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    FIT_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * h->npad, s));
-    FIT_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
-    FIT_HIP(hipStreamSynchronize(s));   // sw / h->w are stack/handle memory: make the copies complete before returning paths
-    if ((rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
-
-    h->external_factor = true;
-    h->L = L_dev;
-    h->Dinv = dinv_dev;
-    h->diagL = diag_dev;
-    h->jitter = jitter;
-    static const bool use_wavefront = getenv("GPX_TRSV_WAVEFRONT") && getenv("GPX_TRSV_WAVEFRONT")[0] == '1';
-    // The single-launch wavefront solves (trsv.hip) are correct but measured slower than the per-step kernels on
-    // MI355X (hand-off + reduction latency on the 128-step critical path: 10 ms vs 5.8 ms at N=16384): opt-in only.
-    if (use_wavefront && h->nblk <= 2048) {   // every workgroup must be resident: 256 CUs x 8 small workgroups
-        int solve_err = 0;
-        if ((rc = trsv_wavefront_pair(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->alpha, h->info_dev + 2, 1, h->info_dev + 1, s, &h->prof))) return fail(rc);
-        FIT_HIP(hipMemcpyAsync(&solve_err, h->info_dev + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        FIT_HIP(hipStreamSynchronize(s));
-        if (solve_err) { gpx_set_error("wavefront triangular solve timed out waiting for a producer workgroup"); return fail(GPX_ERR_HIP); }
-    } else {
-        if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
-        if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
-        FIT_HIP(hipStreamSynchronize(s));
-    }
-#undef FIT_HIP
-    *out = h;
-    return 0;
+    const ExternalFactor ext{L_dev, dinv_dev, diag_dev, jitter};
+    return make_handle(x, t_centered, n, d, theta, stream, &ext, out);
 }
 
 #define CHECK_H(h)                                                  \
