@@ -7,30 +7,14 @@
 // row-major panels ("NT"), which is what a row-major lower-triangular factor gives for L L^T-type
 // products.
 //
-// Tiling: 128x128 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles of 16x16 (16
-// independent accumulators, 128 VGPRs).  k is staged 16 deep through double-buffered LDS with one
-// barrier per stage; global loads are 16 B/lane with 8 lanes covering one 128-B row segment; LDS
-// rows are padded to an odd stride (17 doubles) so the ds_read2_b64 fragment reads (lane l -> row l&15,
-// k l>>4) are bank-conflict free.  LDS 68 KiB/block -> 2 blocks per CU.
+// Tiling: 128x128 block tile, 4 waves (2x2), 64x64 per wave = 4x4 MFMA tiles of 16x16 (16 independent accumulators,
+// 128 VGPRs), two workgroups per CU.  k is staged 16 deep through double-buffered LDS filled by LDS-DMA; the inner loop
+// is described at the kernel.  An earlier 128x256 / one-wave-per-SIMD variant (AGPR-pinned inline-asm MFMAs, three LDS
+// buffers) topped out at 67 TFLOP/s against 75 for this one and was removed.
 #include <stdlib.h>
 
 #include "common.h"
 
-// MFMA issue.  For the 32-accumulator (128x256) tile the accumulators must live in AGPRs; hipcc 7.2 then copies
-// them VGPR<->AGPR around every builtin MFMA (and spills), so that variant issues the instruction through inline
-// asm with the accumulator pinned to the AGPR class ("+a").  Hazards the assembler would otherwise pad are
-// covered by construction: operands come from LDS reads (waitcnt by the compiler), an accumulator is reused
-// only after 31 other MFMAs, and gpx_acc_fence() separates the last MFMA from the first accumulator read.
-#ifdef GPX_GEMM_STAMP
-__device__ unsigned long long gpx_stamp_sink[5];
-#endif
-
-template <bool ASM>
-__device__ __forceinline__ void gpx_mma(v4d &acc, double a, double b)
-{
-    if constexpr (ASM) asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-    else acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-}
 // pin a wave-uniform pointer into SGPRs (so that global_load_lds takes the "SGPR base + 32-bit VGPR offset" form)
 __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
 {
@@ -38,20 +22,14 @@ __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<const char *>(((unsigned long)hi << 32) | lo);
 }
-__device__ __forceinline__ void gpx_acc_fence(v4d &a0, v4d &a1, v4d &a2, v4d &a3, v4d &a4, v4d &a5, v4d &a6, v4d &a7)
-{
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(a0), "+a"(a1), "+a"(a2), "+a"(a3), "+a"(a4), "+a"(a5), "+a"(a6), "+a"(a7));
-}
-
 // WM x WN = MFMA tiles per wave (rows x cols); the block tile is (32 WM) x (32 WN) with 2x2 waves.
 // (4,4) -> 128x128, the bulk kernel; (2,2) -> 64x64 and (2,4)/(1,4) -> 64x128 / 32x128 for the short, skinny
 // products on the factorisation's critical path, where a 128-tile grid would leave most of the 256 CUs idle
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 template <int WM, int WN, bool LOWER>
-__global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
                                                             double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim)
 {
-    constexpr bool BIG = (WM * WN > 16);          // 32 accumulators: AGPR-pinned inline-asm MFMA path
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
     // ONE LDS array: per stage an A image [BTM][16] and a B image [BTN][16] of doubles (128-byte rows, no padding),
@@ -60,7 +38,7 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     // the SOURCE address and again on the fragment reads: the 32 lanes of a ds_read_b64 half then hit 32
     // distinct 8-byte slots of the 256-byte bank row.
     constexpr int STAGE = (BTM + BTN) * 16;
-    constexpr int NBUF = BIG ? 3 : 2;             // BIG: one workgroup per CU -> room for a third buffer, DMA two stages ahead
+    constexpr int NBUF = 2;
     __shared__ __attribute__((aligned(1024))) double smem[NBUF * STAGE];
 
     int bx, by;   // bx: column tile, by: row tile
@@ -145,7 +123,6 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     }
 
     const int nk = (K - (int)kstart) / GEMM_BK;
-    constexpr int NDMA = (BTM / 8 + 3) / 4 + (BTN / 8 + 3) / 4;   // LDS-DMA instructions per wave per stage
     GPX_DMA_STAGE(0, 0)
     // C enters through the accumulators: acc0 = (beta/alpha) C, result = alpha (acc0 + A B^T).  The tile's read
     // overlaps the first DMA stage instead of sitting, dependent, in the epilogue (matters for the K = 128..512
@@ -169,15 +146,8 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
 #pragma unroll
             for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
     }
-    if constexpr (BIG) {
-        if (nk > 1) GPX_DMA_STAGE(1, 1)
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0 has landed (the asm DMA is invisible to hipcc)
-        __syncthreads();
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stage 0 has landed (the asm DMA is invisible to hipcc)
+    __syncthreads();
 
     // fragment addresses: row-local swizzle term depends on the lane only ((row>>1)&7 == (fr>>1)&7 because the
     // wave/tile row offsets are multiples of 16)
@@ -189,9 +159,7 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
     const int b_row = BTM * 16 + (wc * WTN + fr) * 16;
 
     // Software pipeline.  Per 16-deep stage t:
-    //   top      : LDS-DMA of a later stage into a free buffer (no VGPR staging, no ds_write pass)
-    //              2 buffers: stage t+1;  3 buffers (BIG): stage t+2, drained with a COUNTED vmcnt so one stage
-    //              of loads stays in flight across the barrier
+    //   top      : LDS-DMA of stage t+1 into the other buffer (no VGPR staging, no ds_write pass)
     //   slices   : fragments double buffered in registers one 4-deep k-slice ahead of the MFMAs
     //   barrier  : BEFORE the last slice's MFMAs, so the first fragments of stage t+1 are read while they run
     double fa[2][WM], fb[2][WN];
@@ -209,10 +177,10 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
 #define GPX_MMA(SET)                                                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < WM; ++i_)                                  \
         _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
-            gpx_mma<BIG>(acc[i_][j_], fa[SET][i_], fb[SET][j_]);
+            acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i_], fb[SET][j_], acc[i_][j_], 0, 0, 0);
 
     GPX_LOAD_FRAGS(0, 0, 0)
-    if constexpr (!BIG) {
+    {
         // two buffers, the stage loop unrolled by two: buffer offsets are immediates of the ds_read_b64 / M0 values, so the
         // steady state issues no vector instruction besides MFMAs, fragment reads and the DMA
 #define GPX_KSTEP(CUR_OFF, NXT_OFF, NXT_BUF, KT)                                        \
@@ -239,51 +207,11 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             if (kt + 1 < nk) GPX_KSTEP(STAGE, 0, 0, kt + 1)
         }
 #undef GPX_KSTEP
-    } else {
-    int cur = 0;                                   // buffer index of stage kt
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nxt = (cur + 1 == NBUF) ? 0 : cur + 1;
-        const int cur_off = cur * STAGE, nxt_off = nxt * STAGE;
-        const bool has_next = kt + 1 < nk;
-        {
-            const int far = (nxt + 1 == NBUF) ? 0 : nxt + 1;
-            if (kt + 2 < nk) GPX_DMA_STAGE(far, kt + 2)
-        }
-        GPX_LOAD_FRAGS(1, cur_off, 1)
-        GPX_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        GPX_LOAD_FRAGS(0, cur_off, 2)
-        GPX_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-        GPX_LOAD_FRAGS(1, cur_off, 3)
-        GPX_MMA(0)
-        __builtin_amdgcn_sched_barrier(0);
-        // stage kt+1 must have landed; the DMA of stage kt+2 (the NDMA youngest operations) may stay in flight
-        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) { GPX_LOAD_FRAGS(0, nxt_off, 0) }
-        GPX_MMA(1)
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nxt;
-    }
     }
 #undef GPX_LOAD_FRAGS
 #undef GPX_MMA
 #undef GPX_DMA_STAGE
 
-    if constexpr (BIG) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            static_assert(!BIG || WN == 8 || WM == 8, "fence helper takes 8 accumulators at a time");
-            if constexpr (WN == 8) gpx_acc_fence(acc[i][0], acc[i][1], acc[i][2], acc[i][3], acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
-        }
-        if constexpr (WM == 8 && WN != 8) {
-#pragma unroll
-            for (int j = 0; j < WN; ++j) gpx_acc_fence(acc[0][j], acc[1][j], acc[2][j], acc[3][j], acc[4][j], acc[5][j], acc[6][j], acc[7][j]);
-        }
-    }
     // epilogue: pure stores
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -293,15 +221,6 @@ __global__ __launch_bounds__(256, (WM * WN > 16) ? 1 : 2) void gemm_nt_f64_kerne
             for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
 }
 
-#ifdef GPX_GEMM_STAMP
-extern "C" int gpx_stamp_read(unsigned long long *out)
-{
-    GPX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(gpx_stamp_sink), sizeof(unsigned long long) * 5));
-    unsigned long long z[5] = {0, 0, 0, 0, 0};
-    GPX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(gpx_stamp_sink), z, sizeof(z)));
-    return 0;
-}
-#endif
 
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
 constexpr double SMALL_GRID_TILES = 192.0;
@@ -350,12 +269,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
                                (long)ldc, (int)K, alpha, beta, 0, 0);                                                    \
     } while (0)
-    static const int big_mode = getenv("GPX_GEMM_BIG") ? atoi(getenv("GPX_GEMM_BIG")) : 0;
-    if (big_mode == 3 && !lower_only) GPX_LAUNCH(2, 4);          // experiments: force a tile shape
-    else if (big_mode == 4 && !lower_only) GPX_LAUNCH(2, 2);
-    else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 1 && N % 256 == 0) GPX_LAUNCH(4, 8);
-    else if (tiles >= 2 * SMALL_GRID_TILES && !lower_only && big_mode == 2 && M % 256 == 0) GPX_LAUNCH(8, 4);
-    else if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
+    if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);
