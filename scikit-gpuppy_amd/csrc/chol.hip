@@ -106,11 +106,6 @@ __device__ __forceinline__ void potrf128_body(double *A, long ld, double *diag_o
     }
 }
 
-__global__ __launch_bounds__(256) void potrf128_kernel(double *A, long ld, double *diag_out, int *info, int col_offset)
-{
-    __shared__ double Ls[2][TILE];
-    potrf128_body(A, ld, diag_out, info, col_offset, Ls);
-}
 
 // ------------------------------------------------------------------------------------------------
 // trtri128: X = L^-1 for a 128x128 lower-triangular L (row-major, ld) -> dinv[128][128] (ld 128).
@@ -244,11 +239,6 @@ __device__ __forceinline__ void trtri128_levels(const double *L, long ld, double
     }
 }
 
-__global__ __launch_bounds__(256) void trtri128_kernel(const double *L, long ld, double *dinv)
-{
-    __shared__ __attribute__((aligned(16))) double X[36 * XB];
-    trtri128_body(L, ld, dinv, X);
-}
 
 // leaf = factor + inverse in ONE launch (one fewer kernel boundary on the factorisation's critical path); the
 // factor travels from the first half to the second through global memory behind a workgroup barrier.
