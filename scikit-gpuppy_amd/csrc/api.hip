@@ -371,6 +371,7 @@ extern "C" void gpx_free(gpx_handle *h)
         else stream_release(h->s_pan, 1);
     }
     if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
+    if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, 1); }
     if (h->leaf.stream) { (void)hipStreamSynchronize(h->leaf.stream); stream_release(h->leaf.stream, 0); }
     if (h->leaf.flags) dfree(h->leaf.flags);
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, 0); }
@@ -382,7 +383,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, &h->leaf));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, &h->leaf, h->s_top));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -418,6 +419,7 @@ static void setup_lookahead_streams(gpx_handle *h)
         h->s_bulk = nullptr;
     }
     h->s_pan = stream_acquire(1);
+    h->s_top = stream_acquire(1);   // pipelined top-slice solves (chol.hip, TopPipe)
     static const int worker_on = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;
     if (h->s_pan && worker_on && (h->leaf.stream = stream_acquire(0))) {
         double *fl = nullptr;

@@ -781,10 +781,31 @@ constexpr int64_t CHOL_NBP = 8;
 // factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
 // steps j in [j0,j1) of the diagonal square [B0,B1): leaf (factor + inverse), in-place TRSM leaf of the rows below
 // inside the square, rank-128 update of the square's remaining columns -- the latency-bound chain of small kernels
-static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
-                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, unsigned long long *worker_flags = nullptr)
+// Optional pipelining of the "top slice": the rows [r0, r1) below the square (the next panel's diagonal-square rows) are
+// solved against the square's triangle column by column on a second stream, each column as soon as the chain step that
+// produces its diagonal-block inverse has finished -- instead of one recursive TRSM after the whole chain.
+struct TopPipe {
+    hipStream_t stream = nullptr;
+    int64_t r0 = 0, r1 = 0;                 // block rows of the slice
+    std::vector<hipEvent_t> *events = nullptr;   // owned by the caller, destroyed after the final synchronisation
+};
+
+// column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
+static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double *Dinv, const TopPipe *top, Profiler *prof)
 {
-    (void)B0;
+    double *Zt = L + (top->r0 * TILE) * ld;
+    const int64_t M = (top->r1 - top->r0) * TILE;
+    if (j > B0)
+        GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
+                               -1.0, 1.0, 0, top->stream, prof));
+    return launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0,
+                          top->stream, prof);
+}
+
+static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
+                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, unsigned long long *worker_flags = nullptr,
+                             const TopPipe *top = nullptr)
+{
     for (int64_t j = j0; j < j1; ++j) {
         if (worker_flags) {   // the persistent leaf worker factors block j; this stream only hands it over and waits
             hipLaunchKernelGGL(leaf_signal_wait_kernel, dim3(1), dim3(64), 0, s, worker_flags, (int)j);
@@ -793,11 +814,20 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
             GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
                                       info_dev, (int)(j * TILE), s, prof));
         const int64_t rows_below = B1 - (j + 1);
-        if (rows_below <= 0) continue;
-        double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
-        GPX_TRY(launch_gemm_nt(Z, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Z, ld, rows_below * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof));
-        GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
-                               rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
+        if (rows_below > 0) {
+            double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
+            GPX_TRY(launch_gemm_nt(Z, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Z, ld, rows_below * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof));
+            GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
+                                   rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
+        }
+        if (top && top->stream && top->r1 > top->r0) {
+            hipEvent_t e;
+            GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            top->events->push_back(e);
+            GPX_HIP(hipEventRecord(e, s));
+            GPX_HIP(hipStreamWaitEvent(top->stream, e, 0));
+            GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof));
+        }
     }
     return 0;
 }
@@ -814,7 +844,7 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw)
+                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw, hipStream_t s_top)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr)
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
@@ -832,14 +862,19 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     }
     const int64_t P = (int64_t)Bs.size() - 1;
     auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
-    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P);
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
+    static const int pipe_last = getenv("GPX_CHOL_PIPETOP") ? atoi(getenv("GPX_CHOL_PIPETOP")) : 1 << 20;   // trailing panels with a pipelined top slice (default: all; 0 = one recursive TRSM after the chain)
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
     for (int64_t p = 0; p < P; ++p) {
         GPX_HIP(hipEventCreateWithFlags(&ev_pf[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_next[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_bulk[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_top[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_tu[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_first[p], hipEventDisableTiming));
     }
+    GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
     if (!s_bulk) s_bulk = s;
     int rc = 0;
     // the leaf worker is bypassed under full profiling (its leaves are not separate launches that events could bracket)
@@ -862,8 +897,18 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             hipLaunchKernelGGL(leaf_worker_kernel, dim3(1), dim3(256), 0, lw->stream, L, (long)ld, Dinv, diagL, info_dev, 0, (int)nblk, wf);
             GPX_HIP(hipGetLastError());
         }
+        std::vector<TopPipe> tops(P + 1);
+        auto piped = [&](int64_t q) { return s_top && pipe_last > 0 && !merged_update && q >= P - pipe_last && bnd(q + 1) < nblk && s_bulk == s; };
+        for (int64_t q = 0; q < P; ++q) {
+            tops[q].stream = piped(q) ? s_top : nullptr;
+            tops[q].r0 = bnd(q + 1);
+            tops[q].r1 = bnd(q + 2);
+            tops[q].events = &top_events;
+        }
+        if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL,
-                                  info_dev, s_pan, prof, wf_chain));
+                                  info_dev, s_pan, prof, wf_chain, &tops[0]));
+        if (piped(0)) { GPX_HIP(hipEventRecord(ev_top[0], s_top)); }
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
@@ -872,7 +917,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             const int64_t K = (B1 - B0) * TILE;
             // (1) top slice first: only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next
             //     chain, so they are solved / updated before anything else and the side stream starts early
-            GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (B2 - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
+            if (piped(p)) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
+            else GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (B2 - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
             GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
                                    -1.0, 1.0, 0, s, prof));
@@ -881,6 +927,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // so neither stream starves while the other's launches are being queued
             GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
+            if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
                 // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
                 GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
@@ -893,6 +940,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 } else {
                 GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                        K, -1.0, 1.0, 0, s, prof));
+                if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its top slice may start (first column now)
+                    GPX_HIP(hipEventRecord(ev_tu[p], s));
+                    GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
+                    GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
+                    GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
+                }
                 if (s_bulk != s) GPX_HIP(hipStreamWaitEvent(s_bulk, ev_next[p], 0));
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                        (nblk - B2) * TILE, K, -1.0, 1.0, 1, s_bulk, prof));
@@ -902,7 +955,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
                 }
             }
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, wf_chain, &tops[p + 1]));
+            if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
         return 0;
@@ -956,6 +1010,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         const unsigned long long one = 1;
         (void)hipMemcpy(wf + 2, &one, sizeof(one), hipMemcpyHostToDevice);
     }
+    if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
     if (wf) {
         (void)hipStreamSynchronize(lw->stream);
@@ -968,7 +1023,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     if (s_bulk != s) (void)hipStreamSynchronize(s_bulk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
-    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_bulk[p]); }
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_bulk[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
+    (void)hipEventDestroy(ev_top[P]);
+    for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     return rc;
 }
 

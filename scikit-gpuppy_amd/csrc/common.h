@@ -78,6 +78,7 @@ struct gpx_handle {
     hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
     LeafWorker leaf;               // persistent leaf worker of the factorisation (stream + hand-off words)
     bool masked_streams = false;   // s_pan / s_bulk were created with CU masks (not cacheable)
+    hipStream_t s_top = nullptr;   // pipelined top-slice solves of the factorisation (opt-in)
 
     double *x = nullptr;        // [n, d] raw inputs
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
@@ -123,7 +124,8 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 
 // recursive blocked algorithms (chol.hip)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw = nullptr);
+                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw = nullptr,
+                hipStream_t s_top = nullptr);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
