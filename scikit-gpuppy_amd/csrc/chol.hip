@@ -882,6 +882,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     unsigned long long *wf = (lw && lw->stream && lw->flags && worker_mode && !(prof && prof->level >= 2)) ? lw->flags : nullptr;
     unsigned long long *wf_chain = (worker_mode == 2) ? nullptr : wf;   // experiment: 2 = worker resident but idle, ordinary leaves
     static const int merged_update = getenv("GPX_CHOL_MERGED") ? atoi(getenv("GPX_CHOL_MERGED")) : 0;   // 1: narrow update + bulk as one trapezoid launch (measured: no gain)
+    static const int pipe_all = getenv("GPX_CHOL_PIPEALL") ? atoi(getenv("GPX_CHOL_PIPEALL")) : 1;   // 1: all rows below the square are solved column by column with the chain; 0: only the top slice
     auto run = [&]() -> int {
         if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
         // Per outer panel p the main stream runs, in order:
@@ -902,7 +903,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         for (int64_t q = 0; q < P; ++q) {
             tops[q].stream = piped(q) ? s_top : nullptr;
             tops[q].r0 = bnd(q + 1);
-            tops[q].r1 = bnd(q + 2);
+            tops[q].r1 = pipe_all ? nblk : bnd(q + 2);
             tops[q].events = &top_events;
         }
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
@@ -930,7 +931,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
                 // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
-                GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
+                if (!(pipe_all && piped(p))) GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
                 if (s_bulk == s && merged_update) {
                     // ONE launch for the rest of panel p+1's columns AND the bulk: a trapezoid whose first B2 - B1 tile
