@@ -372,8 +372,6 @@ extern "C" void gpx_free(gpx_handle *h)
     }
     if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
     if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, 1); }
-    if (h->leaf.stream) { (void)hipStreamSynchronize(h->leaf.stream); stream_release(h->leaf.stream, 0); }
-    if (h->leaf.flags) dfree(h->leaf.flags);
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, 0); }
     delete h;
 }
@@ -383,7 +381,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, &h->leaf, h->s_top));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, h->s_top));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -397,7 +395,7 @@ static void setup_lookahead_streams(gpx_handle *h)
 {
     // The diagonal chain of the next panel runs on a second, high-priority stream underneath the main stream's work.
     // GPX_RESERVED_CUS > 0 instead reserves CUs for it with CU masks (measured slower on ROCm 7.2: excluding one CU per
-    // XCD costs the bulk 12 %, tools/probe_cumask.py), GPX_LEAF_WORKER = 1 adds the persistent leaf worker (opt-in).
+    // XCD costs the bulk 12 %, tools/probe_cumask.py).
     int ncu = 0;
     (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
     int reserve = 0;
@@ -420,11 +418,6 @@ static void setup_lookahead_streams(gpx_handle *h)
     }
     h->s_pan = stream_acquire(1);
     h->s_top = stream_acquire(1);   // pipelined top-slice solves (chol.hip, TopPipe)
-    static const int worker_on = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;
-    if (h->s_pan && worker_on && (h->leaf.stream = stream_acquire(0))) {
-        double *fl = nullptr;
-        if (dalloc(&fl, 4) == 0) h->leaf.flags = reinterpret_cast<unsigned long long *>(fl);
-    }
 }
 
 static int make_handle(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,

@@ -532,74 +532,6 @@ __global__ __launch_bounds__(256) void potrf_trtri128_mfma_kernel(double *A, lon
     leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Xd, Gs, &bad_s);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Leaf worker: ONE persistent workgroup that owns a whole CU for the duration of a factorisation and factors the
-// diagonal blocks k0..k1-1 as they become ready.  A leaf launched as an ordinary kernel lands on a CU that also runs a
-// bulk GEMM workgroup and crawls (fp64 VALU and the GEMM's fp64 MFMAs share the SIMD: 135 us average instead of 47 us
-// alone); the worker's LDS footprint (157 KB) keeps every GEMM workgroup (64 KB) off its CU.  The chain stream
-// replaces each leaf launch by a one-wave kernel that posts go = k+1 and waits for done = k+1; hand-offs are
-// agent-scope release/acquire on device memory.  Every wait has a wall-clock timeout, and an abort word, so all waves
-// reach their exit whatever the host does.
-//   flags[0] = go (blocks ready), flags[1] = done (blocks factored), flags[2] = abort, flags[3] = timeout seen
-// ------------------------------------------------------------------------------------------------
-constexpr long long LEAF_TIMEOUT_TICKS = 20LL * 100000000LL;   // 20 s of the 100 MHz wall clock
-
-// Polling uses RELAXED agent-scope loads: an acquire load is followed by an L2 invalidate (buffer_inv sc1) on every
-// iteration, which wipes the XCD's L2 under the GEMM workgroups sharing it a few million times per second.  One acquire
-// fence after the flag has been seen is enough.
-__device__ __forceinline__ bool leaf_wait_ge(unsigned long long *word, unsigned long long target, unsigned long long *flags)
-{
-    const long long t0 = wall_clock64();
-    for (;;) {
-        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
-        if (__hip_atomic_load(&flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-        if (wall_clock64() - t0 > LEAF_TIMEOUT_TICKS) {
-            __hip_atomic_store(&flags[3], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(16);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return true;
-}
-
-__global__ __launch_bounds__(256) void leaf_worker_kernel(double *L, long ld, double *Dinv, double *diagL, int *info, int k0, int k1,
-                                                         unsigned long long *flags)
-{
-    __shared__ __attribute__((aligned(16))) double X[36 * XB];
-    __shared__ __attribute__((aligned(16))) double Xd[8 * XB];
-    __shared__ __attribute__((aligned(16))) double Gs[XB];
-    __shared__ __attribute__((aligned(16))) double pad_lds[7400];   // 59 KB of ballast: no 64-KB GEMM workgroup fits next to this one
-    __shared__ int bad_s;
-    __shared__ int go_s;
-    const int t = threadIdx.x;
-    if (k1 < 0) {   // never true: keeps the ballast allocated
-        pad_lds[t] = (double)t;
-        __syncthreads();
-        diagL[0] = pad_lds[(t + 1) & 255];
-    }
-    for (int k = k0; k < k1; ++k) {
-        if (t == 0) go_s = leaf_wait_ge(&flags[0], (unsigned long long)(k + 1), flags) ? 1 : 0;
-        __syncthreads();
-        if (!go_s) return;                                    // abort / timeout: uniform exit
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // every thread: the block written by earlier kernels is visible
-        leaf_mfma_body(L + ((long)k * TILE) * ld + (long)k * TILE, ld, Dinv + (long)k * TILE * TILE, diagL + (long)k * TILE, info,
-                       k * TILE, X, Xd, Gs, &bad_s);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(&flags[1], (unsigned long long)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-// chain-stream side of the hand-off: post "block k is ready", wait until the worker has factored it
-__global__ __launch_bounds__(64) void leaf_signal_wait_kernel(unsigned long long *flags, int k)
-{
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&flags[0], (unsigned long long)(k + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        (void)leaf_wait_ge(&flags[1], (unsigned long long)(k + 1), flags);
-    }
-}
-
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof)
 {
@@ -803,16 +735,11 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
 }
 
 static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
-                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, unsigned long long *worker_flags = nullptr,
-                             const TopPipe *top = nullptr)
+                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, const TopPipe *top = nullptr)
 {
     for (int64_t j = j0; j < j1; ++j) {
-        if (worker_flags) {   // the persistent leaf worker factors block j; this stream only hands it over and waits
-            hipLaunchKernelGGL(leaf_signal_wait_kernel, dim3(1), dim3(64), 0, s, worker_flags, (int)j);
-            GPX_HIP(hipGetLastError());
-        } else
-            GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE,
-                                      info_dev, (int)(j * TILE), s, prof));
+        GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE, info_dev,
+                                  (int)(j * TILE), s, prof));
         const int64_t rows_below = B1 - (j + 1);
         if (rows_below > 0) {
             double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
@@ -844,22 +771,14 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw, hipStream_t s_top)
+                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, hipStream_t s_top)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr)
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                   : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
-    // outer panel boundaries (block units): GPX_CHOL_WIDE = w,r -> panels of w blocks while more than r blocks remain, then CHOL_NBP
+    // outer panel boundaries (block units).  Wider early panels (12..32 blocks) were measured and are slower.
     std::vector<int64_t> Bs{0};
-    {
-        static const char *wenv = getenv("GPX_CHOL_WIDE");
-        int64_t wide = CHOL_NBP, until = 0;
-        if (wenv) { long a = 0, b = 0; if (sscanf(wenv, "%ld,%ld", &a, &b) == 2 && a >= 1) { wide = a; until = b; } }
-        while (Bs.back() < nblk) {
-            const int64_t rem = nblk - Bs.back();
-            Bs.push_back(std::min<int64_t>(nblk, Bs.back() + (rem > until ? wide : CHOL_NBP)));
-        }
-    }
+    while (Bs.back() < nblk) Bs.push_back(std::min<int64_t>(nblk, Bs.back() + CHOL_NBP));
     const int64_t P = (int64_t)Bs.size() - 1;
     auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
@@ -877,14 +796,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
     if (!s_bulk) s_bulk = s;
     int rc = 0;
-    // the leaf worker is bypassed under full profiling (its leaves are not separate launches that events could bracket)
-    static const int worker_mode = getenv("GPX_LEAF_WORKER") ? atoi(getenv("GPX_LEAF_WORKER")) : 0;   // opt-in: measured slower overall
-    unsigned long long *wf = (lw && lw->stream && lw->flags && worker_mode && !(prof && prof->level >= 2)) ? lw->flags : nullptr;
-    unsigned long long *wf_chain = (worker_mode == 2) ? nullptr : wf;   // experiment: 2 = worker resident but idle, ordinary leaves
     static const int merged_update = getenv("GPX_CHOL_MERGED") ? atoi(getenv("GPX_CHOL_MERGED")) : 0;   // 1: narrow update + bulk as one trapezoid launch (measured: no gain)
     static const int pipe_all = getenv("GPX_CHOL_PIPEALL") ? atoi(getenv("GPX_CHOL_PIPEALL")) : 1;   // 1: all rows below the square are solved column by column with the chain; 0: only the top slice
     auto run = [&]() -> int {
-        if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
         // Per outer panel p the main stream runs, in order:
         //   TRSM of rows [B1,B2) of panel p + update of panel p+1's diagonal square  -> event: the side stream starts
         //   TRSM of the remaining rows of panel p, update of the remaining rows of panel p+1's columns,
@@ -893,11 +807,6 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // CUs, pure latency) underneath all of that.
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
-        if (wf) {
-            GPX_HIP(hipStreamWaitEvent(lw->stream, ev0, 0));
-            hipLaunchKernelGGL(leaf_worker_kernel, dim3(1), dim3(256), 0, lw->stream, L, (long)ld, Dinv, diagL, info_dev, 0, (int)nblk, wf);
-            GPX_HIP(hipGetLastError());
-        }
         std::vector<TopPipe> tops(P + 1);
         auto piped = [&](int64_t q) { return s_top && pipe_last > 0 && !merged_update && q >= P - pipe_last && bnd(q + 1) < nblk && s_bulk == s; };
         for (int64_t q = 0; q < P; ++q) {
@@ -908,7 +817,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         }
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL,
-                                  info_dev, s_pan, prof, wf_chain, &tops[0]));
+                                  info_dev, s_pan, prof, &tops[0]));
         if (piped(0)) { GPX_HIP(hipEventRecord(ev_top[0], s_top)); }
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
@@ -927,7 +836,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
                 // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
@@ -956,71 +865,15 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
                 }
             }
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, wf_chain, &tops[p + 1]));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1]));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
         return 0;
     };
-    // Schedule 2: the side stream owns a panel completely -- diagonal chain, then the TRSM of ALL rows below -- and
-    // runs it underneath the previous panel's bulk SYRK (which never touches this panel's columns); the main stream
-    // only issues the two trailing updates per panel: the next panel's columns first (that is what releases the side
-    // stream), then the bulk.
-    auto run2 = [&]() -> int {
-        if (wf) GPX_HIP(hipMemsetAsync(wf, 0, 4 * sizeof(unsigned long long), s));
-        GPX_HIP(hipEventRecord(ev0, s));
-        GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
-        if (wf) {
-            GPX_HIP(hipStreamWaitEvent(lw->stream, ev0, 0));
-            hipLaunchKernelGGL(leaf_worker_kernel, dim3(1), dim3(256), 0, lw->stream, L, (long)ld, Dinv, diagL, info_dev, 0, (int)nblk, wf);
-            GPX_HIP(hipGetLastError());
-        }
-        for (int64_t p = 0; p < P; ++p) {
-            const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
-            // side stream: panel p (its columns are complete once ev_next[p-1] has fired)
-            if (p > 0) GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p - 1], 0));
-            GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s_pan, prof, wf_chain));
-            if (B1 < nblk) GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s_pan, prof));
-            GPX_HIP(hipEventRecord(ev_pf[p], s_pan));
-            if (B1 >= nblk) break;
-            // main stream: trailing updates with panel p
-            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));
-            const int64_t K = (B1 - B0) * TILE;
-            const double *Pall = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows >= B1
-            // next panel's columns: its diagonal square (lower tiles) and everything below it
-            GPX_TRY(launch_gemm_nt(Pall, ld, Pall, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
-                                   -1.0, 1.0, 1, s, prof));
-            if (B2 < nblk) {
-                const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
-                GPX_TRY(launch_gemm_nt(Pr, ld, Pall, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
-                                       K, -1.0, 1.0, 0, s, prof));
-            }
-            GPX_HIP(hipEventRecord(ev_next[p], s));
-            if (B2 < nblk) {
-                const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;
-                GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
-                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
-            }
-        }
-        GPX_HIP(hipStreamWaitEvent(s, ev_pf[P - 1], 0));
-        return 0;
-    };
-    static const int sched = getenv("GPX_CHOL_SCHED") ? atoi(getenv("GPX_CHOL_SCHED")) : 1;   // 2 = opt-in experiment, measured slower
-    rc = (sched == 2) ? run2() : run();
-    if (wf && (rc || worker_mode == 2)) {   // the host gave up half-way: release the worker and whoever waits for it
-        const unsigned long long one = 1;
-        (void)hipMemcpy(wf + 2, &one, sizeof(one), hipMemcpyHostToDevice);
-    }
+    rc = run();
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
-    if (wf) {
-        (void)hipStreamSynchronize(lw->stream);
-        unsigned long long timed_out = 0;
-        if (hipMemcpy(&timed_out, wf + 3, sizeof(timed_out), hipMemcpyDeviceToHost) == hipSuccess && timed_out && !rc) {
-            gpx_set_error("Cholesky leaf worker hand-off timed out");
-            rc = GPX_ERR_HIP;
-        }
-    }
     if (s_bulk != s) (void)hipStreamSynchronize(s_bulk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);

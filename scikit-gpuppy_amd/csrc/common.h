@@ -58,12 +58,6 @@ struct ProfScope {
 };
 
 // ---- the fitted model held in HBM ------------------------------------------------------------
-// persistent leaf worker (chol.hip): its own stream and four device words (go, done, abort, timeout)
-struct LeafWorker {
-    hipStream_t stream = nullptr;
-    unsigned long long *flags = nullptr;
-};
-
 struct gpx_handle {
     int device = 0;
     int64_t n = 0, npad = 0, nblk = 0;
@@ -76,9 +70,8 @@ struct gpx_handle {
     bool external_factor = false;   // L / Dinv / diagL belong to the caller (gpx_adopt_factor)
     hipStream_t s_pan = nullptr;   // side stream for the latency-bound diagonal chain (CU-masked: a few reserved CUs)
     hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
-    LeafWorker leaf;               // persistent leaf worker of the factorisation (stream + hand-off words)
     bool masked_streams = false;   // s_pan / s_bulk were created with CU masks (not cacheable)
-    hipStream_t s_top = nullptr;   // pipelined top-slice solves of the factorisation (opt-in)
+    hipStream_t s_top = nullptr;   // pipelined panel solves of the factorisation (chol.hip, TopPipe)
 
     double *x = nullptr;        // [n, d] raw inputs
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
@@ -124,8 +117,7 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 
 // recursive blocked algorithms (chol.hip)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, const LeafWorker *lw = nullptr,
-                hipStream_t s_top = nullptr);
+                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, hipStream_t s_top = nullptr);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
