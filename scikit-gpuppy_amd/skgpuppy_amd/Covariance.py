@@ -230,10 +230,10 @@ class _SPGPDeviceModel(object):
             raise RuntimeError("device model already released")
         return self._h
 
-    def close(self):
+    def close(self, _free=_gpx.lib.gpx_spgp_free, _null=ctypes.c_void_p):
         if getattr(self, "_h", None):
-            _gpx.lib.gpx_spgp_free(self._h)
-            self._h = ctypes.c_void_p()
+            _free(self._h)
+            self._h = _null()
 
     __del__ = close
 

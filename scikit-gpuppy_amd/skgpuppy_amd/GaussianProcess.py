@@ -29,10 +29,11 @@ class _DeviceModel(object):
             raise RuntimeError("device model already released")
         return self._h
 
-    def close(self):
+    def close(self, _free=_gpx.lib.gpx_free, _null=ctypes.c_void_p):
+        # (defaults bound at definition time: the module globals may already be gone when __del__ runs at interpreter exit)
         if getattr(self, "_h", None):
-            _gpx.lib.gpx_free(self._h)
-            self._h = ctypes.c_void_p()
+            _free(self._h)
+            self._h = _null()
 
     __del__ = close
 

@@ -260,9 +260,12 @@ class ShardedGaussianProcess(object):
         _gpx.check(st, "gpx_adopt_factor")
 
     def close(self):
-        from . import _gpx
         if getattr(self, "_h", None):
-            _gpx.lib.gpx_free(self._h)
+            try:
+                from . import _gpx
+                _gpx.lib.gpx_free(self._h)
+            except Exception:      # interpreter shutdown: the module table is already being torn down
+                pass
             self._h = ctypes.c_void_p()
         self._ops = None
 
