@@ -772,3 +772,30 @@ def test_two_threads_two_handles():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not errs, errs
+
+
+def test_jitter_fallback_on_the_lookahead_path():
+    """same fallback at a size that takes the multi-stream look-ahead factorisation with pipelined panel solves
+    (N > 1024): a cluster of near-duplicates in the THIRD panel makes a pivot non-positive well into the factorisation;
+    the first attempt must report it (not hang, not return garbage) and the retry on K + 1e-5 I must succeed; non-finite
+    hyper-parameters are refused."""
+    rng = np.random.RandomState(11)
+    N, d = 3000, 3
+    x = rng.uniform(0, 10, (N, d))
+    x[2300:2420] = x[2300] + 1e-9 * rng.randn(120, d)          # 120 numerically identical rows
+    t = np.sin(x.sum(1))
+    theta = np.array([0.5, -np.inf, -1.0, -1.0, -1.0])          # vt = 0
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta)
+    assert gp._dev().jitter() == 1e-5
+    mean, var = gp.estimate_many(x[:50])
+    assert np.all(np.isfinite(mean)) and np.all(np.isfinite(var))
+    with np.errstate(divide="ignore"):
+        og_K = orc.gram(x, theta) + 1e-5 * np.eye(N)
+    alpha = np.linalg.solve(og_K, t - t.mean())
+    np.testing.assert_allclose(gp._get_beta(), alpha, rtol=0, atol=1e-5 * np.abs(alpha).max())
+    xx = x.copy()
+    xx[:, :] = xx[0]                                             # all inputs identical: K = v 11^T, rank one
+    gp2 = sk.GaussianProcess(xx, t, sk.GaussianCovariance(), theta)
+    assert gp2._dev().jitter() == 1e-5
+    with pytest.raises(ValueError):      # scipy.linalg.inv's check_finite raises ValueError in the reference as well
+        sk.GaussianProcess(x, t, sk.GaussianCovariance(), np.array([np.nan, -1.0, -1.0, -1.0, -1.0]))
