@@ -595,8 +595,11 @@ static int trtri_upper_rec(double *Z, int64_t ldz, const double *L, int64_t ldl,
     }
     const int64_t h = split_point(nb), cm = c0 + h;
     GPX_TRY(trtri_upper_rec(Z, ldz, L, ldl, Dinv, c0, cm, s, prof));
+    // Z[0:cm, c0:cm) is upper triangular below row c0 (Z[r][k] = 0 for k < r): row tiles past c0 start their k loop at
+    // their own first row (ktrim shift = c0 * 128) -- at the top level that halves the launch
+    static const int trim = getenv("GPX_TRTRI_TRIM") ? atoi(getenv("GPX_TRTRI_TRIM")) : 1;
     GPX_TRY(launch_gemm_nt(Z + c0 * TILE, ldz, L + (cm * TILE) * ldl + c0 * TILE, ldl, Z + cm * TILE, ldz, cm * TILE,
-                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof));
+                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof, 0, trim ? (int)(c0 * TILE) + 1 : 0));
     return trtri_upper_rec(Z, ldz, L, ldl, Dinv, cm, c1, s, prof);
 }
 

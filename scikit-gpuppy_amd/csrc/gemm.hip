@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         const int orig = blockIdx.y * gx + blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
-        const int lid = (LOWER && ktrim) ? orig : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
+        const int lid = ktrim ? orig : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
         if (LOWER) {
             // 1-D grid over the needed tiles only (row-major), so every XCD chunk carries the same number of tiles.
             // Row by holds the tiles bx <= by + tri_off: tri_off = 0 is the lower triangle of a square C; tri_off > 0 a
@@ -83,7 +83,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     const int drow = lane >> 3;
     // ktrim (lower-only launches): both operands are UPPER triangular in their own index space (operand[i][k] = 0 for
     // k < i), so tile (by, bx <= by) contracts over k >= by * BTM only -- K^-1 = L^-T L^-1 as one launch
-    const long kstart = (LOWER && ktrim) ? (long)by * BTM : 0;
+    // Rectangular launches: A alone is upper triangular with its diagonal shifted by ktrim - 1 columns to the left of its
+    // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
+    // k = max(0, by * BTM - (ktrim - 1)).
+    long kstart = 0;
+    if (ktrim) {
+        kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
+        if (kstart < 0) kstart = 0;
+        if (kstart > K) kstart = K;
+    }
     const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda + kstart);
     const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb + kstart);
     unsigned aoff[(BTM / 8 + 3) / 4], boff[(BTN / 8 + 3) / 4];
@@ -243,8 +251,12 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: lower_only needs N >= M (square C, or a trapezoid with N - M full columns on the left)");
         return GPX_ERR_BAD_ARG;
     }
-    if (ktrim && (!lower_only || N != M || K != M)) {
-        gpx_set_error("launch_gemm_nt: ktrim needs a square lower-only launch with K == M");
+    if (ktrim && lower_only && (N != M || K != M)) {
+        gpx_set_error("launch_gemm_nt: ktrim on a lower-only launch needs a square C with K == M");
+        return GPX_ERR_BAD_ARG;
+    }
+    if (ktrim && !lower_only && (ktrim - 1) % GEMM_BK) {
+        gpx_set_error("launch_gemm_nt: ktrim shift must be a multiple of %d", GEMM_BK);
         return GPX_ERR_BAD_ARG;
     }
     const int64_t trap = lower_only ? N - M : 0;   // full columns left of the triangle
@@ -267,7 +279,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                                (long)ldc, (int)K, alpha, beta, (int)off_, ktrim);                                            \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, 0, 0);                                                    \
+                               (long)ldc, (int)K, alpha, beta, 0, ktrim);                                                    \
     } while (0)
     if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
