@@ -15,7 +15,9 @@ N>1 : one rank per GPU (torch.distributed over RCCL), config C4 (N=65536, d=16) 
 The JSON line also carries
   roofline     : the dominant kernel (fp64 MFMA GEMM) timed live with HIP events on the handle's stream
   cpu_baseline : the oracle (CPU restatement of the reference algorithm, "port") timed on the host
-                 cores on a bounded sample of the same workload (rank 0, N=1 only).
+                 cores on the FULL workload when that fits --cpu-budget seconds (rank 0, N=1 only), and
+  parity_vs_oracle : the GPU outputs of the timed workload compared with the oracle's.
+  python_api   : the same workload through the user-facing classes, host arrays in and out.
 """
 import argparse
 import ctypes
@@ -52,18 +54,73 @@ def recipe(N, d, M):
     return x, t, xs, theta
 
 
-def cpu_baseline(d, budget_n=5120):
-    """Time the oracle (same algorithm class as the reference: tile/GEMM Gram, LU inverse, GEMM-based
-    estimate_many with the M x M products) on a bounded sample of the workload."""
+def host_info():
+    """CPU model, visible cores and the BLAS thread count the oracle's numpy/scipy calls use."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count()
+    blas = []
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [{"lib": i.get("internal_api"), "threads": i.get("num_threads")} for i in threadpool_info()]
+    except Exception:
+        pass
+    threads = max([b["threads"] for b in blas if b["lib"] in ("openblas", "mkl", "blis")] or [affinity])
+    return {"cpu_model": model, "os_cpu_count": os.cpu_count(), "sched_affinity": affinity, "blas": blas, "blas_threads": threads}
+
+
+def cpu_baseline(N, d, M, budget_s=300.0):
+    """Time the oracle (same algorithm class as the reference: tile/GEMM Gram, LU inverse, GEMM-based estimate_many with
+    the M x M products) on the host cores.  The FULL workload is run when a 2048-point probe predicts (cubically) that it
+    fits `budget_s`; otherwise the largest multiple of 1024 that does.  Returns sizes, stage times, and the oracle's outputs."""
     from oracle import oracle as orc
-    N = M = budget_n
-    x, t, xs, theta = recipe(N, d, M)
+    xw, tw, xsw, thw = recipe(512, d, 512)
+    orc.OracleGP(xw, tw, thw).estimate_many(xsw)          # imports, BLAS thread start-up
+    xp, tp_, xsp, thp = recipe(2048, d, 2048)
+    t0 = time.perf_counter()
+    orc.OracleGP(xp, tp_, thp).estimate_many(xsp)
+    probe = time.perf_counter() - t0
+    Ns = N
+    while Ns > 2048 and probe * (Ns / 2048.0) ** 3 > budget_s:
+        Ns -= 1024
+    Ms = M if Ns == N else Ns
+    x, t, xs, theta = recipe(Ns, d, Ms) if Ns != N else recipe(N, d, M)
     t0 = time.perf_counter()
     gp = orc.OracleGP(x, t, theta)
     t1 = time.perf_counter()
-    gp.estimate_many(xs)
+    mean, var = gp.estimate_many(xs)
     t2 = time.perf_counter()
-    return N, M, t1 - t0, t2 - t1
+    return {"N": Ns, "M": Ms, "fit_s": t1 - t0, "predict_s": t2 - t1, "probe_2048_s": probe, "mean": mean, "var": var,
+            "inputs": (x, t, xs, theta)}
+
+
+def python_api_section(N, d, M, reps=2):
+    """Second figure (predict outputs copied to the host): the user-facing classes with NumPy inputs and NumPy
+    outputs -- GaussianProcess(x, t, GaussianCovariance(), theta) + estimate_many(xs) -- PCIe copies included."""
+    import skgpuppy_amd as sk
+    x, t, xs, theta = recipe(N, d, M)
+    best = None
+    for _ in range(reps + 1):     # first repetition warms the allocator
+        a = time.perf_counter()
+        gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+        b = time.perf_counter()
+        mean, var = gp.estimate_many(xs)
+        c = time.perf_counter()
+        gp._dev().close()
+        if best is None or c - a < best[0]:
+            best = (c - a, b - a, c - b)
+    return {"value": (N + M) / best[0], "unit": "pts/s", "fit_ms": best[1] * 1e3, "estimate_many_ms": best[2] * 1e3,
+            "note": "GaussianProcess(...) + estimate_many(...) through the Python classes, host arrays in, host arrays out"}, mean, var
 
 
 def propagate_section(lib, _gpx, vp, xd, td, th, N, d):
@@ -247,20 +304,46 @@ def run_single(args):
     }
     if not args.no_propagate:
         out["propagate"] = propagate_section(lib, _gpx, vp, xd, td, th, N, d)
+    if not args.no_python_api:
+        out["python_api"], mean_py, var_py = python_api_section(N, d, M)
     if not args.no_cpu:
-        Ns, Ms, tf, tp = cpu_baseline(d)
-        v_s = (Ns + Ms) / (tf + tp)
-        scale = (N / Ns) ** 3
+        cb = cpu_baseline(N, d, M, budget_s=args.cpu_budget)
+        Ns, Ms, tf, tp = cb["N"], cb["M"], cb["fit_s"], cb["predict_s"]
+        hi = host_info()
+        full = (Ns == N and Ms == M)
         out["cpu_baseline"] = {
-            "value": v_s,
+            "value": (Ns + Ms) / (tf + tp),
             "unit": "pts/s",
-            "cores": os.cpu_count(),
+            "cores": hi["blas_threads"],
             "kind": "port",
-            "sample": "oracle (numpy/scipy restatement of the reference algorithm) on N=M=%d d=%d of the same recipe: "
-                      "fit %.2f s + estimate_many %.2f s; cubic extrapolation to N=M=%d: %.1f pts/s" % (
-                          Ns, d, tf, tp, N, (N + M) / ((tf + tp) * scale)),
-            "extrapolated_full_workload_value": (N + M) / ((tf + tp) * scale),
+            "sample": ("the FULL workload (N=M=%d d=%d)" % (Ns, d) if full else
+                       "N=M=%d d=%d of the same recipe (the full workload was predicted to exceed the %.0f s budget)" % (Ns, d, args.cpu_budget))
+                      + ": oracle (numpy/scipy restatement of the reference algorithm: GEMM-expansion Gram, LU inverse, "
+                        "GEMM estimate_many incl. the M x M products) fit %.2f s + estimate_many %.2f s" % (tf, tp),
+            "full_workload": full,
+            "fit_s": tf, "estimate_many_s": tp, "probe_2048_s": cb["probe_2048_s"],
+            "host": hi,
         }
+        if not full:
+            scale = (N / Ns) ** 3
+            out["cpu_baseline"]["extrapolated_full_workload_value"] = (N + M) / ((tf + tp) * scale)
+        # parity of what was just timed: the GPU path on the oracle's inputs against the oracle's outputs (SURVEY 8a tolerances)
+        xo, to_, xso, tho = cb["inputs"]
+        if full:
+            gm, gv = mean_d.cpu().numpy() + to_.mean(), var_d.cpu().numpy()
+        else:
+            import skgpuppy_amd as sk
+            gpo = sk.GaussianProcess(xo, to_, sk.GaussianCovariance(), tho.copy())
+            gm, gv = gpo.estimate_many(xso)
+            gpo._dev().close()
+        v_ = float(np.exp(tho[0]))
+        em, ev = float(np.abs(gm - cb["mean"]).max()), float(np.abs(gv - cb["var"]).max())
+        ok = bool(np.allclose(gm, cb["mean"], rtol=1e-6, atol=1e-9 * v_) and np.allclose(gv, cb["var"], rtol=1e-6, atol=1e-9 * v_))
+        out["parity_vs_oracle"] = {"workload": "N=M=%d d=%d" % (Ns, d), "max_abs_dmean": em, "max_abs_dvar": ev,
+                                   "tolerance": "rtol 1e-6, atol 1e-9 v", "ok": ok}
+        if not ok:
+            print(json.dumps(out))
+            raise SystemExit("bench.py: GPU outputs differ from the oracle beyond tolerance: %r" % (out["parity_vs_oracle"],))
     print(json.dumps(out))
 
 
@@ -270,11 +353,19 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default=None)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and the parity check against it)")
+    ap.add_argument("--cpu-budget", type=float, default=300.0, help="seconds the CPU baseline may take (full workload if it fits)")
+    ap.add_argument("--no-python-api", action="store_true", help="skip the second figure through the Python classes")
     ap.add_argument("--no-propagate", action="store_true", help="skip the (untimed) propagate_GA section")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit("bench.py --gpus %d needs one rank per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+    rehearsal = bool(os.environ.get("GPX_BENCH_SHARDED"))    # diagnostic: the sharded code path with ONE rank (world size 1)
+    if args.gpus != world and not rehearsal:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 or world > 1 or rehearsal:
         from skgpuppy_amd import distributed as dist_mod
         dist_mod.bench_main(args)
         return

@@ -83,6 +83,7 @@ int gpx_alpha(gpx_handle *h, double *beta_out);     /* beta = K^-1 t  [n]   (Gau
 int gpx_kinv(gpx_handle *h, double *Kinv_out);      /* K^-1 [n,n], materialised lazily on device
                                                        (GaussianProcess.Kinv attribute, :41, :152-164) */
 int gpx_chol(gpx_handle *h, double *L_out);         /* lower Cholesky factor [n,n] (zeros above the diagonal) */
+int gpx_chol_rows(gpx_handle *h, int64_t r0, int64_t r1, double *L_out);   /* rows [r0,r1) of it: [r1-r0, n] */
 
 /* ---- a9-a11: C_ux / J_ux / H_ux for a propagation input u
  * (skgpuppy/UncertaintyPropagation.py:504-510; Covariance.py:440-451, :660-689) ----

@@ -394,6 +394,35 @@ def spgp_nll(x, t, theta, m):
             + np.log(ep).sum() / 2.0 + 0.5 * N * np.log(2 * np.pi))
 
 
+def spgp_nll_chunked(x, t, theta, m, chunk=32768):
+    """spgp_nll (Covariance.py:981-1019) with the N-long contractions accumulated over column chunks of K_MN, so that
+    BASELINE config 5 (N = 262144, M = 2048) needs ~1.5 GB of host memory instead of ~30 GB.  Same formula, same jitter;
+    pinned against spgp_nll in tests/test_oracle_golden.py."""
+    x = np.asarray(x, dtype=float)
+    N, d = x.shape
+    tg, xm = spgp_split(theta, d, m)
+    v, vt, _w = unpack_theta(tg)
+    y = np.asarray(t, dtype=float)
+    L = cholesky(gram_ij(xm, xm, tg) + 1e-6 * np.eye(m), lower=True)
+    VVt = np.zeros((m, m))
+    Vy = np.zeros(m)
+    yy = 0.0
+    logep = 0.0
+    for c0 in range(0, N, chunk):
+        V = solve_triangular(L, gram_ij(xm, x[c0:c0 + chunk], tg), lower=True)
+        ep = 1.0 + (v - (V ** 2).sum(0)) / vt
+        V = V / np.sqrt(ep)[None, :]
+        yc = y[c0:c0 + chunk] / np.sqrt(ep)
+        VVt += np.dot(V, V.T)
+        Vy += np.dot(V, yc)
+        yy += np.dot(yc, yc)
+        logep += np.log(ep).sum()
+    Lm = cholesky(vt * np.eye(m) + VVt, lower=True)
+    bet = solve_triangular(Lm, Vy, lower=True)
+    return (np.log(np.diag(Lm)).sum() + (N - m) / 2.0 * np.log(vt) + (yy - np.dot(bet, bet)) / 2.0 / vt
+            + logep / 2.0 + 0.5 * N * np.log(2 * np.pi))
+
+
 def spgp_generic_nll(x, t, theta, m):
     """Base-class likelihood on the dense SPGP covariance  (Covariance.py:197-216 with :814-833)."""
     K = spgp_cov_matrix(x, theta, m)

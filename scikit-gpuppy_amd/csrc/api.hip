@@ -35,7 +35,7 @@ int launch_exact_build(const double *x, int64_t n, int64_t npad, int d, const do
 
 // ---- error text -----------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-static int g_device = 0;
+static thread_local int g_device = 0;   // per host thread: gpx_set_device selects the device of handles created by THIS thread
 
 void gpx_set_error(const char *fmt, ...)
 {
@@ -66,7 +66,7 @@ extern "C" int gpx_set_device(int device)
     return 0;
 }
 
-static int require_device()
+int gpx_require_device()
 {
     int n = gpx_device_count();
     if (n == 0) {
@@ -272,10 +272,10 @@ static int ensure_Z(gpx_handle *h, int64_t rows)
     return 0;
 }
 
-__global__ __launch_bounds__(256) void extract_lower_kernel(const double *L, long ld, long n, double *out, long ldo)
+__global__ __launch_bounds__(256) void extract_lower_kernel(const double *L, long ld, long n, long r0, double *out, long ldo)
 {
-    const long i = blockIdx.x;
-    for (long j = threadIdx.x; j < n; j += 256) out[i * ldo + j] = (j <= i) ? L[i * ld + j] : 0.0;
+    const long i = r0 + blockIdx.x;
+    for (long j = threadIdx.x; j < n; j += 256) out[(i - r0) * ldo + j] = (j <= i) ? L[i * ld + j] : 0.0;
 }
 
 // ---- Gram (stand-alone) --------------------------------------------------------------------------
@@ -283,36 +283,41 @@ extern "C" int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_d
                             double add_diag, int lower_only, int pad_identity, double *out_dev, int64_t ld,
                             int64_t rows_pad, int64_t cols_pad, void *stream)
 {
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     double v, vt, w[GPX_MAX_D], sw[GPX_MAX_D];
     GPX_TRY(parse_theta(theta, d, &v, &vt, w));
     if (n1 < 0 || n2 < 0 || !out_dev) { gpx_set_error("gpx_dev_gram: bad sizes"); return GPX_ERR_BAD_ARG; }
     for (int k = 0; k < d; ++k) sw[k] = sqrt(w[k]);
     hipStream_t s = (hipStream_t)stream;
     double *swd = nullptr, *a = nullptr, *b = nullptr;
-    GPX_TRY(dalloc(&swd, d));
-    GPX_HIP(hipMemcpyAsync(swd, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    GPX_TRY(dalloc(&a, std::max<int64_t>(n1, 1) * d));
-    GPX_TRY(launch_scale_rows(xi_dev, n1, n1, d, swd, a, s));
-    if (xj_dev == xi_dev && n1 == n2) b = a;
-    else {
-        GPX_TRY(dalloc(&b, std::max<int64_t>(n2, 1) * d));
-        GPX_TRY(launch_scale_rows(xj_dev, n2, n2, d, swd, b, s));
-    }
-    int rc = launch_gram(a, n1, b, n2, d, v, add_diag, lower_only, pad_identity ? 2 : 1, out_dev, ld, rows_pad, cols_pad, s, nullptr);
-    hipError_t e = hipStreamSynchronize(s);
-    dfree(swd);
-    dfree(a);
-    if (b != a) dfree(b);
+    int rc = 0;
+    hipError_t e = hipSuccess;
+    do {   // single exit: the stream is synchronised before the stack array `sw` and the pool buffers are released
+        if ((rc = dalloc(&swd, d))) break;
+        if ((e = hipMemcpyAsync(swd, sw, sizeof(double) * d, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((rc = dalloc(&a, std::max<int64_t>(n1, 1) * d))) break;
+        if ((rc = launch_scale_rows(xi_dev, n1, n1, d, swd, a, s))) break;
+        if (xj_dev == xi_dev && n1 == n2) b = a;
+        else {
+            if ((rc = dalloc(&b, std::max<int64_t>(n2, 1) * d))) break;
+            if ((rc = launch_scale_rows(xj_dev, n2, n2, d, swd, b, s))) break;
+        }
+        rc = launch_gram(a, n1, b, n2, d, v, add_diag, lower_only, pad_identity ? 2 : 1, out_dev, ld, rows_pad, cols_pad, s, nullptr);
+    } while (0);
+    const hipError_t es = hipStreamSynchronize(s);
+    if (swd) dfree(swd);
+    if (b && b != a) dfree(b);
+    if (a) dfree(a);
     if (rc) return rc;
     GPX_HIP(e);
+    GPX_HIP(es);
     return 0;
 }
 
 extern "C" int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t n2, int d, const double *theta,
                         double add_diag, double *K_out)
 {
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (!xi || !xj || !K_out || n1 < 0 || n2 < 0) { gpx_set_error("gpx_gram: null pointer / negative size"); return GPX_ERR_BAD_ARG; }
     if (n1 == 0 || n2 == 0) return 0;
     double v, vt, w[GPX_MAX_D];
@@ -345,7 +350,7 @@ extern "C" int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t 
 extern "C" int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *dinv, double *diag,
                                   int *info_dev, void *stream)
 {
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (!L || !dinv || !diag || !info_dev || B0 < 0 || B1 <= B0 || B1 > nblk || ld < nblk * TILE) {
         gpx_set_error("gpx_dev_chol_panel: bad arguments");
         return GPX_ERR_BAD_ARG;
@@ -365,12 +370,7 @@ extern "C" void gpx_free(gpx_handle *h)
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
-    if (h->s_pan) {
-        (void)hipStreamSynchronize(h->s_pan);
-        if (h->masked_streams) (void)hipStreamDestroy(h->s_pan);
-        else stream_release(h->s_pan, 1);
-    }
-    if (h->s_bulk) { (void)hipStreamSynchronize(h->s_bulk); (void)hipStreamDestroy(h->s_bulk); }
+    if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); stream_release(h->s_pan, 1); }
     if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, 1); }
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, 0); }
     delete h;
@@ -381,7 +381,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     hipStream_t s = h->stream;
     GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, h->s_bulk, &h->prof, h->s_top));
+    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top));
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -393,31 +393,10 @@ struct ExternalFactor { double *L, *Dinv, *diag; double jitter; };
 
 static void setup_lookahead_streams(gpx_handle *h)
 {
-    // The diagonal chain of the next panel runs on a second, high-priority stream underneath the main stream's work.
-    // GPX_RESERVED_CUS > 0 instead reserves CUs for it with CU masks (measured slower on ROCm 7.2: excluding one CU per
-    // XCD costs the bulk 12 %, tools/probe_cumask.py).
-    int ncu = 0;
-    (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device);
-    int reserve = 0;
-    if (const char *e = getenv("GPX_RESERVED_CUS")) reserve = atoi(e);
-    if (ncu >= 64 && reserve > 0 && reserve < ncu / 2) {
-        const int words = (ncu + 31) / 32;
-        std::vector<uint32_t> m_side(words, 0u), m_bulk(words, 0u);
-        for (int c = 0; c < ncu; ++c) {
-            if (c < reserve) m_side[c >> 5] |= 1u << (c & 31);
-            else m_bulk[c >> 5] |= 1u << (c & 31);
-        }
-        if (hipExtStreamCreateWithCUMask(&h->s_pan, words, m_side.data()) == hipSuccess &&
-            hipExtStreamCreateWithCUMask(&h->s_bulk, words, m_bulk.data()) == hipSuccess) {
-            h->masked_streams = true;
-            return;
-        }
-        (void)hipGetLastError();
-        if (h->s_pan) { (void)hipStreamDestroy(h->s_pan); h->s_pan = nullptr; }
-        h->s_bulk = nullptr;
-    }
+    // The diagonal chain of the next panel runs on a second, high-priority stream underneath the main stream's work;
+    // a third one carries the pipelined panel solves (chol.hip, TopPipe).
     h->s_pan = stream_acquire(1);
-    h->s_top = stream_acquire(1);   // pipelined top-slice solves (chol.hip, TopPipe)
+    h->s_top = stream_acquire(1);
 }
 
 static int make_handle(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
@@ -487,20 +466,10 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
             }
         }
     }
-    // alpha = L^-T (L^-1 t).  The single-launch wavefront solves (trsv.hip) are correct but measured slower than the per-step
-    // kernels on MI355X (hand-off latency on the 128-step critical path): opt-in only.
-    static const bool use_wavefront = getenv("GPX_TRSV_WAVEFRONT") && getenv("GPX_TRSV_WAVEFRONT")[0] == '1';
-    if (use_wavefront && h->nblk <= 2048) {
-        int solve_err = 0;
-        if ((rc = trsv_wavefront_pair(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->alpha, h->info_dev + 2, 1, h->info_dev + 1, s, &h->prof))) return fail(rc);
-        FIT_HIP(hipMemcpyAsync(&solve_err, h->info_dev + 1, sizeof(int), hipMemcpyDeviceToHost, s));
-        FIT_HIP(hipStreamSynchronize(s));
-        if (solve_err) { gpx_set_error("wavefront triangular solve timed out waiting for a producer workgroup"); return fail(GPX_ERR_HIP); }
-    } else {
-        if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
-        if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
-        FIT_HIP(hipStreamSynchronize(s));
-    }
+    // alpha = L^-T (L^-1 t)
+    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
+    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
+    FIT_HIP(hipStreamSynchronize(s));
 #undef FIT_HIP
     *out = h;
     return 0;
@@ -510,7 +479,7 @@ extern "C" int gpx_fit(const double *x, const double *t_centered, int64_t n, int
                        gpx_handle **out)
 {
     if (out) *out = nullptr;
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (!x || !t_centered || !out || n < 1) { gpx_set_error("gpx_fit: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
     return make_handle(x, t_centered, n, d, theta, stream, nullptr, out);
 }
@@ -520,7 +489,7 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
                                 gpx_handle **out)
 {
     if (out) *out = nullptr;
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (!x || !t_centered || !out || n < 1 || !L_dev || !dinv_dev || !diag_dev) { gpx_set_error("gpx_adopt_factor: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
     const ExternalFactor ext{L_dev, dinv_dev, diag_dev, jitter};
     return make_handle(x, t_centered, n, d, theta, stream, &ext, out);
@@ -641,19 +610,26 @@ extern "C" int gpx_kinv(gpx_handle *h, double *Kinv_out)
     return 0;
 }
 
-extern "C" int gpx_chol(gpx_handle *h, double *L_out)
+extern "C" int gpx_chol_rows(gpx_handle *h, int64_t r0, int64_t r1, double *L_out)
 {
     CHECK_H(h);
-    if (!L_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    if (!L_out || r0 < 0 || r1 < r0 || r1 > h->n) { gpx_set_error("gpx_chol_rows: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (r1 == r0) return 0;
     double *tmp = nullptr;
-    GPX_TRY(dalloc(&tmp, h->n * h->n));
-    hipLaunchKernelGGL(extract_lower_kernel, dim3((unsigned)h->n), dim3(256), 0, h->stream, (const double *)h->L,
-                       (long)h->npad, (long)h->n, tmp, (long)h->n);
-    hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * h->n * h->n, hipMemcpyDefault, h->stream);
+    GPX_TRY(dalloc(&tmp, (r1 - r0) * h->n));
+    hipLaunchKernelGGL(extract_lower_kernel, dim3((unsigned)(r1 - r0)), dim3(256), 0, h->stream, (const double *)h->L,
+                       (long)h->npad, (long)h->n, (long)r0, tmp, (long)h->n);
+    hipError_t e = hipMemcpyAsync(L_out, tmp, sizeof(double) * (r1 - r0) * h->n, hipMemcpyDefault, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     dfree(tmp);
     GPX_HIP(e);
     return 0;
+}
+
+extern "C" int gpx_chol(gpx_handle *h, double *L_out)
+{
+    if (!h) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; }
+    return gpx_chol_rows(h, 0, h->n, L_out);
 }
 
 // ---- propagation -----------------------------------------------------------------------------------
@@ -669,9 +645,20 @@ static inline double *out_ptr(gpx_handle *h) { return sigma_ptr(h) + GPX_MAX_D *
 static int ensure_prop_buffers(gpx_handle *h)
 {
     if (h->V) return 0;
-    GPX_TRY(dalloc(&h->V, (int64_t)TILE * h->npad));
-    GPX_HIP(hipMemsetAsync(h->V, 0, sizeof(double) * TILE * h->npad, h->stream));
-    GPX_TRY(dalloc(&h->KV, (int64_t)TILE * h->npad + (int64_t)(h->d + 2) * h->npad + GPX_MAX_D + GPX_MAX_D * GPX_MAX_D + 256));
+    // both buffers are committed to the handle only when both allocations and the clear have been issued
+    double *V = nullptr, *KV = nullptr;
+    GPX_TRY(dalloc(&V, (int64_t)TILE * h->npad));
+    int rc = dalloc(&KV, (int64_t)TILE * h->npad + (int64_t)(h->d + 2) * h->npad + GPX_MAX_D + GPX_MAX_D * GPX_MAX_D + 256);
+    if (rc) { dfree(V); return rc; }
+    if (hipMemsetAsync(V, 0, sizeof(double) * TILE * h->npad, h->stream) != hipSuccess) {
+        (void)hipStreamSynchronize(h->stream);
+        dfree(V);
+        dfree(KV);
+        gpx_set_error("hipMemsetAsync(V) failed");
+        return GPX_ERR_HIP;
+    }
+    h->V = V;
+    h->KV = KV;
     return 0;
 }
 
@@ -700,8 +687,11 @@ static int prepare_u(gpx_handle *h, const double *u)
     if (by_solves) {
         // KV = V K^-1 = (V L^-T) L^-1 on the 128-row block, no K^-1
         if (!h->DinvT) {
-            GPX_TRY(dalloc(&h->DinvT, h->nblk * (int64_t)TILE * TILE));
-            GPX_TRY(launch_transpose_factor(h->L, h->npad, h->nblk, h->Dinv, h->DinvT, s));
+            double *dt = nullptr;
+            GPX_TRY(dalloc(&dt, h->nblk * (int64_t)TILE * TILE));
+            const int rt = launch_transpose_factor(h->L, h->npad, h->nblk, h->Dinv, dt, s);
+            if (rt) { (void)hipStreamSynchronize(s); dfree(dt); return rt; }
+            h->DinvT = dt;   // committed only once the transposed copy has been issued
         }
         GPX_HIP(hipMemcpyAsync(h->KV, h->V, sizeof(double) * TILE * h->npad, hipMemcpyDeviceToDevice, s));
         GPX_TRY(trsm_right_lt(h->KV, h->npad, TILE, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof));
@@ -925,7 +915,7 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(const double *K, long n, 
 
 extern "C" int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, double *logdet_out)
 {
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (!K || !Kinv_out || n < 1) { gpx_set_error("gpx_spd_inverse: bad arguments"); return GPX_ERR_BAD_ARG; }
     const int64_t npad = round_up(n, TILE), nblk = npad / TILE;
     hipStream_t s = nullptr;
@@ -1046,7 +1036,7 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(const v2d *__restrict__ a
 
 extern "C" int gpx_bench_hbm(int64_t bytes, int iters, double *write_gbs, double *copy_gbs)
 {
-    GPX_TRY(require_device());
+    GPX_TRY(gpx_require_device());
     if (bytes < (1 << 20) || iters < 1) { gpx_set_error("gpx_bench_hbm: bytes >= 1 MiB, iters >= 1"); return GPX_ERR_BAD_ARG; }
     const long n16 = bytes / 16;
     v2d *a = nullptr, *b = nullptr;

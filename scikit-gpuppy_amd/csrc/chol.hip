@@ -5,23 +5,16 @@
 // the Kinv GEMV/GEMMs at skgpuppy/GaussianProcess.py:77-78,114-119.  K = L L^T is factored once
 // (N^3/3 flop); everything downstream solves against L.
 //
-// Structure: recursive blocking down to 128x128 diagonal blocks.  All O(N^3) work is issued as calls of
-// the one MFMA GEMM (gemm.hip); the leaves are
-//   potrf128 : one workgroup factors a diagonal block held in REGISTERS (each thread owns an 8x8
-//              cyclic sub-lattice, so the rank-1 updates are pure register FMAs and one LDS column
-//              broadcast + one barrier per pivot), and
-//   trtri128 : inverts the 128x128 factor by recursive doubling over 16x16 blocks on MFMA, so that
-//              every triangular solve against a diagonal block becomes a GEMM with its inverse.
+// Structure: two-level right-looking factorisation with look-ahead down to 128x128 diagonal blocks.  All O(N^3)
+// work is issued as calls of the one MFMA GEMM (gemm.hip); the leaf (potrf_trtri128_mfma_kernel) factors a diagonal
+// block AND inverts its factor in one launch, both on MFMA out of LDS, so that every triangular solve against a
+// diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
 
-// ------------------------------------------------------------------------------------------------
-// potrf128: A (128x128, row-major, ld) -> L in place (lower, zeros above), diag_out[128] = L_jj.
-// Thread t = (ty = t>>4, tx = t&15) owns elements (i = ty + 16a, k = tx + 16b), a,b in [0,8).
-// ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double fast_rsqrt(double d)
 {
     double y = __builtin_amdgcn_rsq(d);        // v_rsq_f64: ~2^-26 relative
@@ -32,233 +25,15 @@ __device__ __forceinline__ double fast_rsqrt(double d)
     return y;
 }
 
-template <int JB>
-__device__ __forceinline__ void potrf128_block_step(double (&acc)[8][8], double (*Ls)[TILE], int tx, int ty,
-                                                   int *bad, int col_offset)
-{
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = 16 * JB + jj;
-        const int buf = j & 1;
-        if (tx == jj) {
-#pragma unroll
-            for (int a = JB; a < 8; ++a) Ls[buf][ty + 16 * a] = acc[a][JB];
-        }
-        __syncthreads();
-        double dj = Ls[buf][j];
-        if (!(dj > 0.0)) {             // non-positive (or NaN) pivot: record the first one, keep going finite
-            if (*bad == 0) *bad = col_offset + j + 1;
-            dj = 1.0;
-        }
-        const double rinv = fast_rsqrt(dj);
-        double li[8], lk[8];
-#pragma unroll
-        for (int a = JB; a < 8; ++a) {
-            const int i = ty + 16 * a;
-            const int k = tx + 16 * a;
-            const double ci = Ls[buf][i] * rinv;
-            const double ck = Ls[buf][k] * rinv;
-            li[a] = (i > j) ? ci : 0.0;
-            lk[a] = (k > j) ? ck : 0.0;
-            if (tx == jj) {            // owner of column j: store the final entries of L[:, j]
-                if (i > j) acc[a][JB] = ci;
-                else if (i == j) acc[a][JB] = dj * rinv;
-            }
-        }
-#pragma unroll
-        for (int a = JB; a < 8; ++a)
-#pragma unroll
-            for (int b = JB; b <= a; ++b) acc[a][b] = fma(-li[a], lk[b], acc[a][b]);
-    }
-}
-
-__device__ __forceinline__ void potrf128_body(double *A, long ld, double *diag_out, int *info, int col_offset, double (*Ls)[TILE])
-{
-    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
-    double acc[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int i = ty + 16 * a, k = tx + 16 * b;
-            acc[a][b] = (b <= a) ? A[(long)i * ld + k] : 0.0;
-        }
-    __syncthreads();
-    int bad = 0;
-    potrf128_block_step<0>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<1>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<2>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<3>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<4>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<5>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<6>(acc, Ls, tx, ty, &bad, col_offset);
-    potrf128_block_step<7>(acc, Ls, tx, ty, &bad, col_offset);
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int i = ty + 16 * a, k = tx + 16 * b;
-            const double val = (k <= i) ? acc[a][b] : 0.0;
-            A[(long)i * ld + k] = val;
-            if (i == k) diag_out[i] = val;
-        }
-    if (bad && t == 0) {   // every thread sees the same pivots; thread 0 reports
-        if (*info == 0) *info = bad;
-    }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// trtri128: X = L^-1 for a 128x128 lower-triangular L (row-major, ld) -> dinv[128][128] (ld 128).
-// Level 0 inverts the eight 16x16 diagonal blocks (16 lanes per block, one column each); levels 1..3
-// double the block size with  X21 = -X22 (L21 X11)  on MFMA 16x16x4 tiles.  The intermediate
-// T = L21 X11 is parked in X21's own (still unused) LDS slot.
-// ------------------------------------------------------------------------------------------------
-// LDS image: the 36 lower-triangular 16x16 blocks only, each padded to 16x17 doubles (odd stride ->
-// conflict-free fragment reads): 78 KB, so the kernel fits on a CU next to a bulk GEMM workgroup instead of
-// waiting for a completely empty CU while the trailing update runs on the other stream.
+// LDS image of a 128x128 lower-triangular block: its 36 lower 16x16 blocks, each padded to 16x17 doubles (odd stride ->
+// conflict-free fragment reads)
 constexpr int XB = 16 * 17;                                  // doubles per packed block
 __device__ __forceinline__ int xblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * XB; }
 
-__device__ __forceinline__ void trtri128_levels(const double *L, long ld, double *dinv, double *X);
-
-__device__ __forceinline__ void trtri128_body(const double *L, long ld, double *dinv, double *X)
-{
-    const int t = threadIdx.x;
-
-    // stage L's eight diagonal 16x16 blocks (zeros above the diagonal)
-    for (int e = t; e < 8 * 256; e += 256) {
-        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        X[xblk(b, b) + r * 17 + c] = (c <= r) ? L[(long)(16 * b + r) * ld + 16 * b + c] : 0.0;
-    }
-    __syncthreads();
-
-    // level 0: thread (b = t>>4, c = t&15), t < 128, solves column c of inv(L_bb) by forward substitution
-    double xcol[16];
-    if (t < 128) {
-        const int b = t >> 4, c = t & 15;
-        const double *Lb = &X[xblk(b, b)];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) s = fma(-Lb[i * 17 + k], xcol[k], s);
-            xcol[i] = s / Lb[i * 17 + i];
-        }
-    }
-    __syncthreads();
-    if (t < 128) {
-        const int b = t >> 4, c = t & 15;
-        double *Xb = &X[xblk(b, b)];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) Xb[i * 17 + c] = xcol[i];   // zero for i < c
-    }
-    __syncthreads();
-    trtri128_levels(L, ld, dinv, X);
-}
-
-// levels 1..3 of the inverse; on entry X's eight diagonal blocks hold inv(L_bb) (zeros above the diagonal)
-__device__ __forceinline__ void trtri128_levels(const double *L, long ld, double *dinv, double *X)
-{
-    const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    // levels s = 1, 2, 4 (block size in 16-units): pairs p of [X11 (s blocks), X22 (s blocks)]
-    for (int s = 1; s <= 4; s <<= 1) {
-        const int npairs = 8 / (2 * s);
-        const int ntask = npairs * s * s;
-        // phase A: T[i][j] = sum_{k=j..s-1} L21[i][k] X11[k][j]   -> parked in X21's own slot
-        v4d res[4];   // at most 4 tasks per wave (ntask <= 16, 4 waves); statically indexed
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s + i;             // block row of X21 / L21
-                const int cb = 2 * s * p;                     // first block col of X11
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = j; k < s; ++k) {
-                    const double *Lg = L + (long)(16 * rb + fr) * ld + 16 * (cb + k) + fq;   // A[row fr][4kk + fq]
-                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // B[4kk + fq][col fr]
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lg[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        // nobody reads X21's blocks in phase A, so T can be stored without a barrier in between
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
-            }
-        }
-        __syncthreads();
-        // phase B: X21[i][j] = - sum_{k=0..i} X22[i][k] T[k][j]
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s;                 // first block row/col of X22 (= first block row of X21 / T)
-                const int cb = 2 * s * p;                     // first block col of X21 / T
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = 0; k <= i; ++k) {
-                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];              // X22[i][k]: A[row fr][4kk + fq]
-                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];              // T[k][j]:  B[4kk + fq][col fr]
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        __syncthreads();   // every read of T is done before X21 overwrites it
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
-            }
-        }
-        __syncthreads();
-    }
-
-    for (int e = t; e < TILE * TILE; e += 256) {
-        const int i = e >> 7, k = e & 127;
-        dinv[e] = ((k >> 4) <= (i >> 4)) ? X[xblk(i >> 4, k >> 4) + (i & 15) * 17 + (k & 15)] : 0.0;
-    }
-}
-
-
-// leaf = factor + inverse in ONE launch (one fewer kernel boundary on the factorisation's critical path); the
-// factor travels from the first half to the second through global memory behind a workgroup barrier.
-__global__ __launch_bounds__(256) void potrf_trtri128_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
-                                                            int col_offset)
-{
-    __shared__ __attribute__((aligned(16))) double X[36 * XB];
-    // the leaf is the latency-critical kernel of the factorisation and usually shares its CU with bulk GEMM waves:
-    // take issue priority over them
-    __builtin_amdgcn_s_setprio(3);
-    potrf128_body(A, ld, diag_out, info, col_offset, reinterpret_cast<double (*)[TILE]>(X));
-    __syncthreads();
-    trtri128_body(A, ld, dinv, X);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Blocked leaf: the same factor + inverse with all O(128^3) work on MFMA.  The register kernel above spends
-// 128 pivots x ~45 dependent fp64 VALU FMAs per wave; when the leaf shares its SIMDs with a bulk GEMM workgroup
-// (it always does under the look-ahead schedule) those VALU instructions queue behind the GEMM's fp64 MFMAs and
-// the leaf runs 2-7x slower.  Here the block lives in LDS as 36 packed 16x16 blocks.  Per 16-column panel, wave 0
+// Leaf: factor + inverse of a 128x128 diagonal block with all O(128^3) work on MFMA (a register-resident VALU
+// formulation queues behind the bulk GEMM's fp64 MFMAs whenever the leaf shares its SIMDs with a bulk workgroup --
+// it always does under the look-ahead schedule -- and ran 2-7x slower).  The block lives in LDS as 36 packed 16x16 blocks.  Per 16-column panel, wave 0
 // eliminates the AUGMENTED 32x16 panel [A_d; I] in registers -- lane (i = lane&15, q = lane>>4) holds columns
 // q, q+4, q+8, q+12 of row i of both halves, multipliers travel by ds_bpermute -- which yields L_d and, from the
 // identity rows, inv(L_d)^T without a separate triangular inversion.  All four waves then apply
@@ -536,11 +311,7 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
                       hipStream_t s, Profiler *prof)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
-    static const int leaf_mode = getenv("GPX_LEAF") ? atoi(getenv("GPX_LEAF")) : 1;   // 0 = register kernel, 1 = blocked MFMA kernel
-    if (leaf_mode == 0)
-        hipLaunchKernelGGL(potrf_trtri128_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
-    else
-        hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
+    hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -597,9 +368,8 @@ static int trtri_upper_rec(double *Z, int64_t ldz, const double *L, int64_t ldl,
     GPX_TRY(trtri_upper_rec(Z, ldz, L, ldl, Dinv, c0, cm, s, prof));
     // Z[0:cm, c0:cm) is upper triangular below row c0 (Z[r][k] = 0 for k < r): row tiles past c0 start their k loop at
     // their own first row (ktrim shift = c0 * 128) -- at the top level that halves the launch
-    static const int trim = getenv("GPX_TRTRI_TRIM") ? atoi(getenv("GPX_TRTRI_TRIM")) : 1;
     GPX_TRY(launch_gemm_nt(Z + c0 * TILE, ldz, L + (cm * TILE) * ldl + c0 * TILE, ldl, Z + cm * TILE, ldz, cm * TILE,
-                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof, 0, trim ? (int)(c0 * TILE) + 1 : 0));
+                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof, 0, (int)(c0 * TILE) + 1));
     return trtri_upper_rec(Z, ldz, L, ldl, Dinv, cm, c1, s, prof);
 }
 
@@ -614,19 +384,7 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
     // ONE lower-only launch whose tile (by, bx) contracts over k >= 128 by only (Z is upper triangular): N^3/3 flop with
     // tiles of length 128 .. N dealt longest-first to whichever workgroup slot frees up (row strips of 1024 with a common
     // k range per strip ran at 49 TFLOP/s: the first strips have few tiles, the last ones short k)
-    static const int strips = getenv("GPX_KINV_STRIPS") ? atoi(getenv("GPX_KINV_STRIPS")) : 0;
-    if (!strips) {
-        GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 0, 1));
-    } else {
-        const int64_t SB = 8;
-        for (int64_t s0 = 0; s0 < nblk; s0 += SB) {
-            const int64_t s1 = std::min<int64_t>(s0 + SB, nblk);
-            const double *A = Z + (s0 * TILE) * npad + s0 * TILE;    // rows of the strip, k from the strip's first row
-            const double *B = Z + s0 * TILE;                          // rows 0..s1, same k range
-            GPX_TRY(launch_gemm_nt(A, npad, B, npad, Kinv + (s0 * TILE) * npad, npad, (s1 - s0) * TILE, s1 * TILE,
-                                   npad - s0 * TILE, 1.0, 0.0, 0, s, prof));
-        }
-    }
+    GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 0, 1));
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }
 
@@ -774,7 +532,7 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, hipStream_t s_top)
+                hipStream_t s_pan, Profiler *prof, hipStream_t s_top)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr)
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
@@ -784,54 +542,48 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     while (Bs.back() < nblk) Bs.push_back(std::min<int64_t>(nblk, Bs.back() + CHOL_NBP));
     const int64_t P = (int64_t)Bs.size() - 1;
     auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
-    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_bulk(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
-    static const int pipe_last = getenv("GPX_CHOL_PIPETOP") ? atoi(getenv("GPX_CHOL_PIPETOP")) : 1 << 20;   // trailing panels with a pipelined top slice (default: all; 0 = one recursive TRSM after the chain)
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
     for (int64_t p = 0; p < P; ++p) {
         GPX_HIP(hipEventCreateWithFlags(&ev_pf[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_next[p], hipEventDisableTiming));
-        GPX_HIP(hipEventCreateWithFlags(&ev_bulk[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_top[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_tu[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_first[p], hipEventDisableTiming));
     }
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
-    if (!s_bulk) s_bulk = s;
-    int rc = 0;
-    static const int merged_update = getenv("GPX_CHOL_MERGED") ? atoi(getenv("GPX_CHOL_MERGED")) : 0;   // 1: narrow update + bulk as one trapezoid launch (measured: no gain)
-    static const int pipe_all = getenv("GPX_CHOL_PIPEALL") ? atoi(getenv("GPX_CHOL_PIPEALL")) : 1;   // 1: all rows below the square are solved column by column with the chain; 0: only the top slice
     auto run = [&]() -> int {
         // Per outer panel p the main stream runs, in order:
-        //   TRSM of rows [B1,B2) of panel p + update of panel p+1's diagonal square  -> event: the side stream starts
-        //   TRSM of the remaining rows of panel p, update of the remaining rows of panel p+1's columns,
-        //   bulk SYRK of everything right of panel p+1
-        // and the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, a few
-        // CUs, pure latency) underneath all of that.
+        //   update of panel p+1's diagonal square (panel p's rows of that square are solved by then) -> event: the side
+        //   stream starts the next chain;  update of the remaining rows of panel p+1's columns;  bulk SYRK of everything
+        //   right of panel p+1
+        // the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, pure latency)
+        // underneath all of that, and the third stream solves ALL rows below panel p's square column by column alongside
+        // panel p's chain (TopPipe), so that neither a top slice nor a panel TRSM remains on the main stream.
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
-        auto piped = [&](int64_t q) { return s_top && pipe_last > 0 && !merged_update && q >= P - pipe_last && bnd(q + 1) < nblk && s_bulk == s; };
+        auto piped = [&](int64_t q) { return s_top && bnd(q + 1) < nblk; };
         for (int64_t q = 0; q < P; ++q) {
             tops[q].stream = piped(q) ? s_top : nullptr;
             tops[q].r0 = bnd(q + 1);
-            tops[q].r1 = pipe_all ? nblk : bnd(q + 2);
+            tops[q].r1 = nblk;
             tops[q].events = &top_events;
         }
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
-        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL,
-                                  info_dev, s_pan, prof, &tops[0]));
-        if (piped(0)) { GPX_HIP(hipEventRecord(ev_top[0], s_top)); }
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0]));
+        if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) break;
             const int64_t K = (B1 - B0) * TILE;
-            // (1) top slice first: only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next
-            //     chain, so they are solved / updated before anything else and the side stream starts early
+            // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
+            //     square before anything else so that the side stream starts early
             if (piped(p)) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
-            else GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (B2 - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
+            else GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
             GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
                                    -1.0, 1.0, 0, s, prof));
@@ -842,31 +594,18 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
-                // (2) the rest of panel p, the rest of panel p+1's columns and the bulk SYRK
-                if (!(pipe_all && piped(p))) GPX_TRY(trsm_right_lt(L + (B2 * TILE) * ld, ld, (nblk - B2) * TILE, L, ld, Dinv, B0, B1, s, prof));
+                // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
-                if (s_bulk == s && merged_update) {
-                    // ONE launch for the rest of panel p+1's columns AND the bulk: a trapezoid whose first B2 - B1 tile
-                    // columns are full (no wave-quantisation tail of a separate 1.75-wave narrow update, no launch boundary)
-                    GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE,
-                                           (nblk - B1) * TILE, K, -1.0, 1.0, 1, s, prof));
-                } else {
                 GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                        K, -1.0, 1.0, 0, s, prof));
-                if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its top slice may start (first column now)
+                if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     GPX_HIP(hipEventRecord(ev_tu[p], s));
                     GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
                     GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
-                if (s_bulk != s) GPX_HIP(hipStreamWaitEvent(s_bulk, ev_next[p], 0));
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
-                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s_bulk, prof));
-                }
-                if (s_bulk != s) {
-                    GPX_HIP(hipEventRecord(ev_bulk[p], s_bulk));
-                    GPX_HIP(hipStreamWaitEvent(s, ev_bulk[p], 0));
-                }
+                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
             }
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1]));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
@@ -874,13 +613,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         }
         return 0;
     };
-    rc = run();
+    const int rc = run();
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
-    if (s_bulk != s) (void)hipStreamSynchronize(s_bulk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
-    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_bulk[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     return rc;

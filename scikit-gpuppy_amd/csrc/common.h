@@ -12,8 +12,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 constexpr int TILE = GPX_TILE;       // 128: diagonal-block size, GEMM block tile
 constexpr int GEMM_BK = 16;          // k-depth of one LDS stage
-constexpr int GEMM_LDS_S = 17;       // padded LDS row stride in doubles: ODD, so the ds_read2_b64 fragment reads the compiler
-                                     // emits (16-lane groups, 32 banks) are conflict free; staged with 8-byte LDS writes
 
 // ---- error plumbing ---------------------------------------------------------------------
 void gpx_set_error(const char *fmt, ...);
@@ -68,9 +66,7 @@ struct gpx_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     bool external_factor = false;   // L / Dinv / diagL belong to the caller (gpx_adopt_factor)
-    hipStream_t s_pan = nullptr;   // side stream for the latency-bound diagonal chain (CU-masked: a few reserved CUs)
-    hipStream_t s_bulk = nullptr;  // bulk trailing-update stream (CU-masked: everything except the reserved CUs)
-    bool masked_streams = false;   // s_pan / s_bulk were created with CU masks (not cacheable)
+    hipStream_t s_pan = nullptr;   // side stream (high priority) for the latency-bound diagonal chain
     hipStream_t s_top = nullptr;   // pipelined panel solves of the factorisation (chol.hip, TopPipe)
 
     double *x = nullptr;        // [n, d] raw inputs
@@ -84,7 +80,7 @@ struct gpx_handle {
     double *y = nullptr;        // [npad] L^-1 t
     double *alpha = nullptr;    // [npad] K^-1 t
     double *Kinv = nullptr;     // [npad, npad] lazily materialised
-    int *info_dev = nullptr;    // [0] potrf info, [1] wavefront-solve error word, [2 .. 2+2*nblk) hand-off flags
+    int *info_dev = nullptr;    // [0] potrf info (1-based failing column, 0 = ok)
     double logdet = 0;
     bool have_logdet = false;
 
@@ -117,7 +113,7 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 
 // recursive blocked algorithms (chol.hip)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, hipStream_t s_pan, hipStream_t s_bulk, Profiler *prof, hipStream_t s_top = nullptr);
+                hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
@@ -132,13 +128,14 @@ int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, 
                  double *scratch, hipStream_t s, Profiler *prof);
 int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,
                   double *scratch, hipStream_t s, Profiler *prof);
-int trsv_wavefront_pair(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
-                        double *a, int *flags, int epoch, int *err_dev, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
 int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
                           double *mean, double *var, hipStream_t s, Profiler *prof);
 int launch_set_identity(double *Z, int64_t ld, int64_t n, hipStream_t s);
 int launch_symmetrize_lower(double *A, int64_t ld, int64_t n, hipStream_t s);
+
+// device selection (api.hip): hipSetDevice to the calling thread's gpx_set_device choice, gfx950 only
+int gpx_require_device();
 
 // caching device allocator and stream cache (api.hip)
 int dalloc(double **p, int64_t elems);

@@ -285,11 +285,7 @@ extern "C" int gpx_spgp_fit(const double *x, const double *t_centered, int64_t n
                             int64_t m, gpx_spgp **out)
 {
     if (out) *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-        gpx_set_error("no HIP device visible: libgpx has no CPU fallback");
-        return GPX_ERR_NO_DEVICE;
-    }
+    GPX_TRY(gpx_require_device());   // the calling thread's gpx_set_device choice + the gfx950 check
     if (!x || !t_centered || !theta || !xb || !out || n < 1 || m < 1 || d < 1 || d > GPX_MAX_D) {
         gpx_set_error("gpx_spgp_fit: bad arguments (n=%ld m=%ld d=%d)", (long)n, (long)m, d);
         return GPX_ERR_BAD_ARG;

@@ -59,6 +59,11 @@ class _DeviceModel(object):
         _gpx.check(_gpx.lib.gpx_chol(self.handle, _gpx.ptr(out)), "gpx_chol")
         return out
 
+    def chol_rows(self, r0, r1):
+        out = np.empty((r1 - r0, self.n))
+        _gpx.check(_gpx.lib.gpx_chol_rows(self.handle, r0, r1, _gpx.ptr(out)), "gpx_chol_rows")
+        return out
+
     def logdet(self):
         v = ctypes.c_double()
         _gpx.check(_gpx.lib.gpx_logdet(self.handle, ctypes.byref(v)), "gpx_logdet")

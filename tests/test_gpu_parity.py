@@ -333,7 +333,7 @@ def test_bad_arguments_raise():
 
 
 # ------------------------------------------------------------------------------------------------
-# BASELINE sizes: size-independent properties (the oracle cannot run these in seconds)
+# BASELINE sizes: size-independent properties (C3/C4: the oracle needs minutes / cannot run them) and full-size oracle parity (C2)
 # ------------------------------------------------------------------------------------------------
 def _recipe(N, d, M):
     rng = np.random.RandomState(20240 + N + d)
@@ -384,10 +384,67 @@ def test_full_size_properties(N, d):
     assert mu == pytest.approx(me, abs=1e-2) and va == pytest.approx(ve, abs=1e-2)
 
 
+def test_c2_full_size_against_oracle():
+    """BASELINE config 2 (N = M = 4096, d = 4) at FULL size against the oracle (LU inverse + GEMM estimate_many + serial
+    double loops: ~5 s on the host), SURVEY 8a tolerances."""
+    N, d = 4096, 4
+    x, t, xs, theta = _recipe(N, d, N)
+    v = 2.0
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    og = orc.OracleGP(x, t, theta)
+    mean, var = gp.estimate_many(xs)
+    om, ov = og.estimate_many(xs)
+    np.testing.assert_allclose(mean, om, rtol=1e-6, atol=1e-9 * v)
+    np.testing.assert_allclose(var, ov, rtol=1e-6, atol=1e-9 * v)
+    beta, obeta = gp._get_beta(), og.beta()
+    np.testing.assert_allclose(beta, obeta, rtol=0, atol=1e-6 * np.abs(obeta).max())
+    assert gp._dev().logdet() == pytest.approx(og.logdet(), rel=1e-10)
+    u, S = np.full(d, 5.0), 0.01 * np.eye(d)
+    ma, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+    oma, ova = orc.approx_propagate(og, u, S)
+    assert ma == pytest.approx(oma, abs=1e-8) and va == pytest.approx(ova, abs=1e-8 * v)
+    me, ve = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
+    ome, ove = orc.exact_propagate(og, u, S)
+    assert me == pytest.approx(ome, abs=1e-8) and ve == pytest.approx(ove, abs=1e-8 * v)
+    np.testing.assert_allclose(gp.Kinv[::97, ::89], og.Kinv[::97, ::89], rtol=0, atol=1e-6 * np.abs(og.Kinv).max())
+
+
+def test_c4_full_size_properties():
+    """BASELINE config 4 (N = 65536, d = 16; K = 34 GB) on ONE GPU through the user-facing classes: the oracle cannot run
+    this size (2 N^3 = 5.6e14 flop), so the checks are the size-independent ones of test_full_size_properties."""
+    N, d = 65536, 16
+    x, t, xs, theta = _recipe(N, d, 2048)
+    v, vt = 2.0, 0.01
+    cov = sk.GaussianCovariance()
+    gp = sk.GaussianProcess(x, t, cov, theta.copy())
+    beta = gp._get_beta()
+    rows = np.random.RandomState(1).choice(N, 512, replace=False)
+    Krows = cov.cov_matrix_ij(x[rows], x, theta)
+    Krows[np.arange(512), rows] += vt
+    assert np.abs(Krows.dot(beta) - gp.t[rows]).max() < 1e-8 * max(1.0, np.abs(beta).max())      # K alpha = t
+    mean, var = gp.estimate_many(x[rows])                                                          # interpolation identity
+    np.testing.assert_allclose(mean - gp.meant, gp.t[rows] - vt * beta[rows], rtol=0, atol=1e-8)
+    assert np.all(var >= vt - 1e-9) and np.all(var < 2 * vt)
+    mf, vf = gp.estimate_many(np.full((1, d), 1e3))                                                # prior far away
+    assert mf[0] == pytest.approx(gp.meant, abs=1e-12) and vf[0] == pytest.approx(v + vt, abs=1e-12)
+    m1, v1 = gp.estimate_many(xs)
+    m2, v2 = gp.estimate_many(xs[::-1])
+    np.testing.assert_array_equal(m1, m2[::-1])
+    np.testing.assert_array_equal(v1, v2[::-1])
+    ma, va = sk.UncertaintyPropagationApprox(gp).propagate_GA(xs[0], 1e-14 * np.eye(d))           # solve path, no K^-1
+    assert ma == pytest.approx(m1[0], abs=1e-8) and va == pytest.approx(v1[0], abs=1e-7)
+    # logdet through an independent route: sum of log pivots == slogdet of a leading 2048 block via numpy on the host
+    Lrows = gp._dev().chol_rows(0, 2048)
+    K0 = cov.cov_matrix(x[:2048], theta)
+    np.testing.assert_allclose(Lrows[:, :2048], np.linalg.cholesky(K0), rtol=0, atol=1e-10)
+    del gp
+    _gpx.lib.gpx_pool_trim()
+
+
 # ------------------------------------------------------------------------------------------------
 # N > 1 code path on the one GPU of the test box: 2 ranks share cuda:0, panels travel over gloo (host staged)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,d", [(2500, 4)])
+@pytest.mark.parametrize("N,d", [(2500, 4), (8200, 6)])      # 8200 rows = 65 blocks = 9 outer panels
 def test_sharded_fit_two_ranks_share_one_gpu(N, d):
     import os
     import subprocess
@@ -636,6 +693,45 @@ def test_spgp_split_k_path():
     want_var = 2.01 - (solve_triangular(Lm, Ks.T, lower=True) ** 2).sum(0) + (solve_triangular(Lb, Ks.T, lower=True) ** 2).sum(0)
     np.testing.assert_allclose(mu, want_mu, rtol=0, atol=2e-5)
     np.testing.assert_allclose(var, want_var, rtol=0, atol=2e-6)
+
+
+def test_c5_spgp_full_size_against_oracle():
+    """BASELINE config 5 at FULL size (N = 262144, M = 2048 pseudo-inputs, d = 8) on one GPU: Snelson's likelihood against
+    the oracle (chunked over N: O(N M^2) = 2.2e12 flop on the host) and the predictor against a numpy transcription of the
+    Woodbury algebra (Covariance.py:835-863 folded into GaussianProcess.estimate_many), both chunked so that no N x M
+    temporary of more than 0.5 GB lives on the host."""
+    from scipy.linalg import cholesky, solve_triangular
+    N, d, m = 262144, 8, 2048
+    rng = np.random.RandomState(20240 + N + d)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    xs = rng.uniform(0, 10, (256, d))
+    th_gc = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    xb = x[rng.choice(N, m, replace=False)].copy()
+    th = np.concatenate([th_gc, xb.ravel()])
+    cov = sk.SPGPCovariance(m)
+    tc = t - t.mean()
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(orc.spgp_nll_chunked(x, tc, th, m), rel=1e-8)
+    gp = sk.GaussianProcess(x, t, cov, th.copy())
+    mu, var = gp.estimate_many(xs)
+    Km = orc.gram_ij(xb, xb, th_gc) + 1e-5 * np.eye(m)
+    Lm = cholesky(Km, lower=True)
+    B = Km.copy()
+    rhs = np.zeros(m)
+    for c0 in range(0, N, 32768):
+        Kc = orc.gram_ij(xb, x[c0:c0 + 32768], th_gc)                          # K_MN chunk
+        lam = 2.0 + 0.01 - (solve_triangular(Lm, Kc, lower=True) ** 2).sum(0)
+        B += (Kc / lam).dot(Kc.T)
+        rhs += (Kc / lam).dot(tc[c0:c0 + 32768])
+    Lb = cholesky(B, lower=True)
+    beta = solve_triangular(Lb, solve_triangular(Lb, rhs, lower=True), lower=True, trans=1)
+    Ks = orc.gram_ij(xs, xb, th_gc)
+    want_mu = Ks.dot(beta) + t.mean()
+    want_var = 2.01 - (solve_triangular(Lm, Ks.T, lower=True) ** 2).sum(0) + (solve_triangular(Lb, Ks.T, lower=True) ** 2).sum(0)
+    np.testing.assert_allclose(mu, want_mu, rtol=0, atol=5e-5)
+    np.testing.assert_allclose(var, want_var, rtol=0, atol=5e-6)
+    del gp
+    _gpx.lib.gpx_pool_trim()
 
 
 def test_approx_propagation_solve_path_equals_kinv_path():

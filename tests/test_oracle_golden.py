@@ -172,6 +172,8 @@ def test_spgp_oracle_matches_reference(name):
     np.testing.assert_allclose(orc.spgp_cov_matrix_ij(xs[:16], x, th, m), g["cross"], rtol=0, atol=1e-12)
     tc = t - t.mean()
     assert orc.spgp_nll(x, tc, th, m) == pytest.approx(float(g["nll_snelson"]), rel=1e-9)
+    # the chunked form used by the full-size config-5 GPU test is the same number (chunk smaller than N on purpose)
+    assert orc.spgp_nll_chunked(x, tc, th, m, chunk=97) == pytest.approx(float(g["nll_snelson"]), rel=1e-9)
     assert orc.spgp_generic_nll(x, tc, th, m) == pytest.approx(float(g["nll_generic"]), rel=1e-6)
     gp = orc.OracleSPGP(x, t, th, m)
     mu, var = gp.estimate_many(xs)
