@@ -366,7 +366,7 @@ extern "C" void gpx_free(gpx_handle *h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->prof.destroy();
     if (h->external_factor) { h->L = nullptr; h->Dinv = nullptr; h->diagL = nullptr; }
-    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV, h->DinvT};
+    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
@@ -426,9 +426,9 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
     if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
         (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) ||
-        (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + h->npad)))
+        (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + 64 * h->npad)))
         return fail(rc);
-    h->small_elems = 4096 + h->npad;
+    h->small_elems = 4096 + 64 * h->npad;   // reductions + the triangular solves' workspace (2 x 32 rows)
     if (ext) {
         h->external_factor = true;
         h->L = ext->L;
@@ -467,8 +467,8 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
         }
     }
     // alpha = L^-T (L^-1 t)
-    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small, s, &h->prof))) return fail(rc);
-    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small, s, &h->prof))) return fail(rc);
+    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small + 4096, s, &h->prof))) return fail(rc);
+    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small + 4096, s, &h->prof))) return fail(rc);
     FIT_HIP(hipStreamSynchronize(s));
 #undef FIT_HIP
     *out = h;
@@ -662,12 +662,12 @@ static int ensure_prop_buffers(gpx_handle *h)
     return 0;
 }
 
-// how many new-u propagations are answered by triangular solves (two recursive TRSMs on a 128-row block, 9 ms at
-// N = 16384) before K^-1 is materialised (66 ms once, then 0.6 ms per new u; break-even after 8 calls): a single
-// propagate_GA after a fit never pays for K^-1, an inverse-propagation loop switches over after a few calls
+// how many new-u propagations are answered by the two streaming triangular solves before K^-1 is materialised
+// (49 ms once at N = 16384, then one pass over it per new u): a single propagate_GA after a fit never pays for
+// K^-1, an inverse-propagation loop switches over after a while
 static int approx_solve_limit()
 {
-    static const int v = getenv("GPX_APPROX_SOLVE_CALLS") ? atoi(getenv("GPX_APPROX_SOLVE_CALLS")) : 6;
+    static const int v = getenv("GPX_APPROX_SOLVE_CALLS") ? atoi(getenv("GPX_APPROX_SOLVE_CALLS")) : 24;
     return v;
 }
 
@@ -685,17 +685,16 @@ static int prepare_u(gpx_handle *h, const double *u)
     GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
     GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
     if (by_solves) {
-        // KV = V K^-1 = (V L^-T) L^-1 on the 128-row block, no K^-1
-        if (!h->DinvT) {
-            double *dt = nullptr;
-            GPX_TRY(dalloc(&dt, h->nblk * (int64_t)TILE * TILE));
-            const int rt = launch_transpose_factor(h->L, h->npad, h->nblk, h->Dinv, dt, s);
-            if (rt) { (void)hipStreamSynchronize(s); dfree(dt); return rt; }
-            h->DinvT = dt;   // committed only once the transposed copy has been issued
+        // KV = V K^-1 row by row: K^-1 v = L^-T (L^-1 v) as two streaming multi-right-hand-side triangular solves
+        // (tsolve.hip) that read the triangle of L once each -- no K^-1, no transposed copy of the factor
+        double *ws = h->small + 4096, *ws2 = ws + 32 * h->npad;
+        const int nrhs = h->d + 1;
+        for (int c0 = 0; c0 < nrhs; c0 += 32) {
+            const int ng = (nrhs - c0 > 16) ? 2 : 1;
+            GPX_HIP(hipMemcpyAsync(ws, h->V + (int64_t)c0 * h->npad, sizeof(double) * 16 * ng * h->npad, hipMemcpyDeviceToDevice, s));
+            GPX_TRY(tsolve_forward(h->L, h->npad, h->Dinv, h->nblk, ws, ws2, h->npad, ng, s, &h->prof));
+            GPX_TRY(tsolve_backward(h->L, h->npad, h->Dinv, h->nblk, ws2, h->KV + (int64_t)c0 * h->npad, h->npad, ng, s, &h->prof));
         }
-        GPX_HIP(hipMemcpyAsync(h->KV, h->V, sizeof(double) * TILE * h->npad, hipMemcpyDeviceToDevice, s));
-        GPX_TRY(trsm_right_lt(h->KV, h->npad, TILE, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof));
-        GPX_TRY(trsm_right_ln(h->KV, h->npad, TILE, h->L, h->npad, h->DinvT, 0, h->nblk, s, &h->prof));
         ++h->approx_solves;
     } else {
         // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6

@@ -388,59 +388,6 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Right solve with L itself (not L^T):  Z[0:rows, c0:c1) <- Z[0:rows, c0:c1) * L[c0:c1, c0:c1]^-1.
-// The GEMM contracts along contiguous k only, so the update  Z_left -= Z_right L[right, left]  needs L^T blocks:
-// launch_transpose_factor stores them once in the (otherwise unused) strictly-upper 128-tiles of the factor's own
-// array -- U[j][c] = L[c][j] -- and the transposed inverse diagonal blocks in DinvT.  Together with trsm_right_lt
-// this gives  V K^-1 = (V L^-T) L^-1  for a block of right-hand-side ROWS without ever forming K^-1.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_factor_kernel(double *L, long ld, long nblk, const double *Dinv, double *DinvT)
-{
-    __shared__ double tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const long bi = blockIdx.y, bj = blockIdx.x;               // 32-blocks of the padded matrix; blockIdx.z == 1: the Dinv tiles
-    if (blockIdx.z == 1) {
-        if (bj >= 4) return;                                    // Dinv is [nblk*128][128]: 4 column blocks
-        const long b = bi >> 2, ri = (bi & 3) * 32, cj = bj * 32;
-        const double *src = Dinv + b * TILE * TILE;
-        double *dst = DinvT + b * TILE * TILE;
-        for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(ri + r) * TILE + cj + tx];
-        __syncthreads();
-        for (int r = ty; r < 32; r += 8) dst[(cj + r) * TILE + ri + tx] = tile[tx][r];
-        return;
-    }
-    if ((bj >> 2) >= (bi >> 2)) return;                         // strictly-lower 128-tiles only
-    for (int r = ty; r < 32; r += 8) tile[r][tx] = L[(bi * 32 + r) * ld + bj * 32 + tx];
-    __syncthreads();
-    for (int r = ty; r < 32; r += 8) L[(bj * 32 + r) * ld + bi * 32 + tx] = tile[tx][r];
-}
-
-int launch_transpose_factor(double *L, int64_t ld, int64_t nblk, const double *Dinv, double *DinvT, hipStream_t s)
-{
-    const unsigned nb32 = (unsigned)(nblk * 4);
-    hipLaunchKernelGGL(transpose_factor_kernel, dim3(nb32, nb32, 2), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, DinvT);
-    GPX_HIP(hipGetLastError());
-    return 0;
-}
-
-int trsm_right_ln(double *Z, int64_t ldz, int64_t rows, const double *LU, int64_t ldl, const double *DinvT,
-                  int64_t c0, int64_t c1, hipStream_t s, Profiler *prof)
-{
-    const int64_t nb = c1 - c0;
-    if (nb <= 0 || rows <= 0) return 0;
-    if (nb == 1) {
-        double *Zc = Z + c0 * TILE;
-        return launch_gemm_nt(Zc, ldz, DinvT + c0 * (int64_t)TILE * TILE, TILE, Zc, ldz, rows, TILE, TILE, 1.0, 0.0, 0, s, prof);
-    }
-    const int64_t h = split_point(nb), cm = c0 + h;
-    GPX_TRY(trsm_right_ln(Z, ldz, rows, LU, ldl, DinvT, cm, c1, s, prof));
-    // Z[:, c0:cm) -= Z[:, cm:c1) * L[cm:c1, c0:cm)  with the B operand read from the transposed copy U[c0:cm, cm:c1)
-    GPX_TRY(launch_gemm_nt(Z + cm * TILE, ldz, LU + (c0 * TILE) * ldl + cm * TILE, ldl, Z + c0 * TILE, ldz, rows,
-                           (cm - c0) * TILE, (c1 - cm) * TILE, -1.0, 1.0, 0, s, prof));
-    return trsm_right_ln(Z, ldz, rows, LU, ldl, DinvT, c0, cm, s, prof);
-}
-
 static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv, double *diagL, int *info_dev,
                     hipStream_t s, Profiler *prof)
 {
@@ -622,157 +569,6 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     return rc;
-}
-
-// ------------------------------------------------------------------------------------------------
-// blocked TRSV for y = L^-1 b and a = L^-T y  (HBM-bound on the triangle of L: 4 N^2 bytes each)
-// One launch per 128-block step; every workgroup first forms the step's solved block from the
-// inverted diagonal block (redundantly: 16K FMA), then applies its own 128x128 off-diagonal block.
-// ------------------------------------------------------------------------------------------------
-// 128x128 tile (row-major, ld) times a 128-vector held in LDS, rows across waves: wave w owns rows 32w..32w+31, every
-// wave-instruction reads one whole 1-KiB row (lane l -> columns 2l, 2l+1), all 32 loads of a wave are issued before
-// the first use (memory-level parallelism), and the 32 per-lane partial sums are reduced by a transposing butterfly
-// (32 shuffles instead of 32 x 6).  Returns, on lanes with (lane & 1) == 0, the finished dot product of row
-//   row_of_lane = 32w + 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1   (b_i = bit i of the lane id).
-__device__ __forceinline__ double tile_matvec_rows(const double *tile, long ld, const double *vec_lds, int wave, int lane)
-{
-    v2d lt[32];
-    const double *base = tile + (long)(32 * wave) * ld + 2 * lane;
-#pragma unroll
-    for (int q = 0; q < 32; ++q) lt[q] = *reinterpret_cast<const v2d *>(base + (long)q * ld);
-    const v2d vv = *reinterpret_cast<const v2d *>(vec_lds + 2 * lane);
-    double p[32];
-#pragma unroll
-    for (int q = 0; q < 32; ++q) p[q] = fma(lt[q].x, vv.x, lt[q].y * vv.y);
-#define GPX_BFLY(HALF, BIT)                                                        \
-    _Pragma("unroll") for (int q = 0; q < HALF; ++q) {                             \
-        const bool up = (lane >> BIT) & 1;                                         \
-        const double send = up ? p[q] : p[q + HALF];                               \
-        const double keep = up ? p[q + HALF] : p[q];                               \
-        p[q] = keep + __shfl_xor(send, 1 << BIT);                                  \
-    }
-    GPX_BFLY(16, 5)
-    GPX_BFLY(8, 4)
-    GPX_BFLY(4, 3)
-    GPX_BFLY(2, 2)
-    GPX_BFLY(1, 1)
-#undef GPX_BFLY
-    return p[0] + __shfl_xor(p[0], 1);
-}
-__device__ __forceinline__ int butterfly_row(int wave, int lane)
-{
-    return 32 * wave + 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 1) & 1);
-}
-
-// forward step k: yk = Dinv_k r_k ; r_{k+1+bid} -= L[k+1+bid, k] yk   (block 0 also stores yk)
-__global__ __launch_bounds__(256) void trsv_fwd_step(const double *L, long ld, const double *Dinv, int k, double *r,
-                                                    double *y)
-{
-    __shared__ __attribute__((aligned(16))) double rk[TILE], yk[TILE];
-    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
-    if (t < TILE) rk[t] = r[(long)k * TILE + t];
-    __syncthreads();
-    {
-        const double s = tile_matvec_rows(Dinv + (long)k * TILE * TILE, TILE, rk, wave, lane);   // zeros above the diagonal
-        if ((lane & 1) == 0) yk[butterfly_row(wave, lane)] = s;
-    }
-    __syncthreads();
-    if (blockIdx.x == 0 && t < TILE) y[(long)k * TILE + t] = yk[t];
-    const long rb = (long)k + 1 + blockIdx.x;   // block row to update (gridDim.x = nblk - k - 1)
-    {
-        const double s = tile_matvec_rows(L + (rb * TILE) * ld + (long)k * TILE, ld, yk, wave, lane);
-        if ((lane & 1) == 0) r[rb * TILE + butterfly_row(wave, lane)] -= s;
-    }
-}
-
-// last forward block (no trailing update) and generic "apply Dinv" : y_k = Dinv_k r_k
-__global__ __launch_bounds__(256) void trsv_diag_only(const double *Dinv, int k, const double *r, double *y, int transpose)
-{
-    __shared__ double rk[TILE];
-    const int t = threadIdx.x;
-    if (t < TILE) rk[t] = r[(long)k * TILE + t];
-    __syncthreads();
-    const int i = t >> 1, half = t & 1;
-    const double *D = Dinv + (long)k * TILE * TILE;
-    double s = 0.0;
-    if (!transpose) {
-        for (int j = half; j <= i; j += 2) s = fma(D[(long)i * TILE + j], rk[j], s);
-    } else {
-        for (int j = i + half; j < TILE; j += 2) s = fma(D[(long)j * TILE + i], rk[j], s);
-    }
-    s += __shfl_xor(s, 1);
-    if (half == 0) y[(long)k * TILE + i] = s;
-}
-
-// transposed 128x128 tile times a 128-vector in LDS, columns across threads: thread (col, half) sums 64 rows of its
-// column; every wave-instruction reads 512 contiguous bytes of one row; all 64 loads are issued before the first use.
-__device__ __forceinline__ double tile_matvecT_cols(const double *tile, long ld, const double *vec_lds, int col, int half)
-{
-    double lt[64];
-    const double *base = tile + (long)(64 * half) * ld + col;
-#pragma unroll
-    for (int q = 0; q < 64; ++q) lt[q] = base[(long)q * ld];
-    const double *vv = vec_lds + 64 * half;
-    double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-    for (int q = 0; q < 64; q += 2) {
-        s0 = fma(lt[q], vv[q], s0);
-        s1 = fma(lt[q + 1], vv[q + 1], s1);
-    }
-    return s0 + s1;
-}
-
-// backward step k: ak = Dinv_k^T s_k ; s_{cb} -= L[k, cb]^T ak  for column block cb = blockIdx.x < k
-__global__ __launch_bounds__(256) void trsv_bwd_step(const double *L, long ld, const double *Dinv, int k, double *sv,
-                                                    double *a)
-{
-    __shared__ double sk[TILE], ak[TILE];
-    __shared__ double part[2][TILE];
-    const int t = threadIdx.x, col = t & 127, half = t >> 7;
-    if (t < TILE) sk[t] = sv[(long)k * TILE + t];
-    __syncthreads();
-    part[half][col] = tile_matvecT_cols(Dinv + (long)k * TILE * TILE, TILE, sk, col, half);   // zeros above the diagonal
-    __syncthreads();
-    if (t < TILE) ak[t] = part[0][t] + part[1][t];
-    __syncthreads();
-    if (blockIdx.x == 0 && t < TILE) a[(long)k * TILE + t] = ak[t];
-    const long cb = blockIdx.x;                 // gridDim.x = k column blocks
-    const double s = tile_matvecT_cols(L + ((long)k * TILE) * ld + cb * TILE, ld, ak, col, half);
-    __syncthreads();
-    part[half][col] = s;
-    __syncthreads();
-    if (t < TILE) sv[cb * TILE + t] -= part[0][t] + part[1][t];
-}
-
-int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
-                 double *scratch, hipStream_t s, Profiler *prof)
-{
-    ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)(nblk * TILE) * (double)(nblk * TILE));
-    GPX_HIP(hipMemcpyAsync(scratch, b, sizeof(double) * nblk * TILE, hipMemcpyDeviceToDevice, s));
-    for (int64_t k = 0; k < nblk; ++k) {
-        if (k + 1 < nblk)
-            hipLaunchKernelGGL(trsv_fwd_step, dim3((unsigned)(nblk - k - 1)), dim3(256), 0, s, L, (long)ld, Dinv, (int)k,
-                               scratch, y);
-        else
-            hipLaunchKernelGGL(trsv_diag_only, dim3(1), dim3(256), 0, s, Dinv, (int)k, (const double *)scratch, y, 0);
-    }
-    GPX_HIP(hipGetLastError());
-    return 0;
-}
-
-int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,
-                  double *scratch, hipStream_t s, Profiler *prof)
-{
-    ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)(nblk * TILE) * (double)(nblk * TILE));
-    GPX_HIP(hipMemcpyAsync(scratch, y, sizeof(double) * nblk * TILE, hipMemcpyDeviceToDevice, s));
-    for (int64_t k = nblk - 1; k >= 0; --k) {
-        if (k > 0)
-            hipLaunchKernelGGL(trsv_bwd_step, dim3((unsigned)k), dim3(256), 0, s, L, (long)ld, Dinv, (int)k, scratch, a);
-        else
-            hipLaunchKernelGGL(trsv_diag_only, dim3(1), dim3(256), 0, s, Dinv, (int)k, (const double *)scratch, a, 1);
-    }
-    GPX_HIP(hipGetLastError());
-    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -91,7 +91,6 @@ struct gpx_handle {
     int64_t small_elems = 0;
 
     // propagate cache (keyed on u)
-    double *DinvT = nullptr;    // transposed inverse diagonal blocks; set once the factor's upper tiles hold L^T (solve path of the propagation)
     int approx_solves = 0;      // new-u propagations served by triangular solves so far (K^-1 is built after a few)
     bool have_u = false;
     double u[GPX_MAX_D];
@@ -119,11 +118,14 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
-int launch_transpose_factor(double *L, int64_t ld, int64_t nblk, const double *Dinv, double *DinvT, hipStream_t s);
-int trsm_right_ln(double *Z, int64_t ldz, int64_t rows, const double *LU, int64_t ldl, const double *DinvT,
-                  int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
+// streaming multi-right-hand-side triangular solves (tsolve.hip); W [16 ng][npad] is destroyed, ng = 1 or 2
+int tsolve_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *Y, int64_t npad, int ng,
+                   hipStream_t s, Profiler *prof);
+int tsolve_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *A, int64_t npad, int ng,
+                    hipStream_t s, Profiler *prof);
+// single right-hand side: scratch holds 32 x (nblk * 128) doubles
 int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
                  double *scratch, hipStream_t s, Profiler *prof);
 int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,

@@ -32,7 +32,7 @@ struct gpx_spgp {
     double *lam = nullptr;   // [npad] lambda_n
     double *ilam = nullptr;  // [npad] 1/sqrt(lambda_n), 0 in the padding
     double *va = nullptr, *vb = nullptr, *vc = nullptr;         // [npad] vector scratch
-    double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad]
+    double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad] ([32 mpad] for mscr)
     double *outd = nullptr;  // [8] scalar results
     int *info = nullptr;
     static constexpr int SPLIT = 8;                 // K-chunks of the tall-skinny product W^T W (K = N)
@@ -228,7 +228,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(dalloc(&h->LM, mp * mp)); GPX_TRY(dalloc(&h->DinvM, tt)); GPX_TRY(dalloc(&h->diagM, mp));
     GPX_TRY(dalloc(&h->LB, mp * mp)); GPX_TRY(dalloc(&h->DinvB, tt)); GPX_TRY(dalloc(&h->diagB, mp));
     GPX_TRY(dalloc(&h->lam, np)); GPX_TRY(dalloc(&h->ilam, np)); GPX_TRY(dalloc(&h->va, np)); GPX_TRY(dalloc(&h->vb, np)); GPX_TRY(dalloc(&h->vc, np));
-    GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
+    GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, 32 * mp));   // tsolve workspace: residual + output, 16 rows each
     GPX_TRY(dalloc(&h->outd, 8));
     {
         double *ib = nullptr;
