@@ -16,7 +16,9 @@
  *     e.g. a torch tensor's data_ptr): copies use hipMemcpyDefault, device pointers are used in place.
  *   - theta = (log v, log vt, log w_1..w_d) exactly as the reference's theta_min, always a host pointer.
  *   - return 0 = ok; >0 = LAPACK-style info (leading minor not positive definite, also after the
- *     +1e-5*I retry that mirrors skgpuppy/Covariance.py:180-185); <0 = bad argument / HIP error
+ *     +1e-5*I retry that mirrors skgpuppy/Covariance.py:180-185.  The reference takes that fallback only when its LU
+ *     inverse raises; here ANY non-positive pivot of the Cholesky factorisation triggers it -- a numerically indefinite
+ *     K that the reference would invert inaccurately gets the documented jitter instead); <0 = bad argument / HIP error
  *     (text via gpx_last_error()).  No exception crosses the ABI.
  *   - a handle is single-owner (one HIP stream, not re-entrant); distinct handles may be used from
  *     distinct threads.  There is NO CPU fallback: without a usable gfx950 device every compute
@@ -80,6 +82,14 @@ int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *mean_out, do
 
 /* ---- a8: accessors ---- */
 int gpx_alpha(gpx_handle *h, double *beta_out);     /* beta = K^-1 t  [n]   (GaussianProcess.py:114-119) */
+/* Kinv . B for a few vectors without forming K^-1 (every `numpy.dot(Kinv, v)` of the reference: GaussianProcess.py:77,
+ * :116, UncertaintyPropagation.py:412-481).  B [nrhs, n]: the right-hand sides as ROWS.  Linv_B_out = L^-1 B and
+ * Kinv_B_out = K^-1 B, both [nrhs, n]; either may be NULL.  Two HBM-bound sweeps over the factor per 32 vectors. */
+int gpx_solve(gpx_handle *h, const double *B, int nrhs, double *Linv_B_out, double *Kinv_B_out);
+/* "next" row f4, GaussianProcess.get_realisation (skgpuppy/GaussianProcess.py:44-57): out[r] = L Z[r] for the rows of
+ * Z [nrhs, n] -- with standard-normal z a draw from N(0, K), K = cov_matrix(x) of the fitted handle (the reference
+ * samples the same distribution through numpy's SVD-based multivariate_normal; the random streams differ). */
+int gpx_chol_mul(gpx_handle *h, const double *Z, int nrhs, double *out);
 int gpx_kinv(gpx_handle *h, double *Kinv_out);      /* K^-1 [n,n], materialised lazily on device
                                                        (GaussianProcess.Kinv attribute, :41, :152-164) */
 int gpx_chol(gpx_handle *h, double *L_out);         /* lower Cholesky factor [n,n] (zeros above the diagonal) */

@@ -365,6 +365,7 @@ extern "C" void gpx_free(gpx_handle *h)
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     h->prof.destroy();
+    h->tri.release();
     if (h->external_factor) { h->L = nullptr; h->Dinv = nullptr; h->diagL = nullptr; }
     double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
     for (double *p : bufs)
@@ -426,9 +427,9 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
     if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
         (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) ||
-        (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + 64 * h->npad)))
+        (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
-    h->small_elems = 4096 + 64 * h->npad;   // reductions + the triangular solves' workspace (2 x 32 rows)
+    h->small_elems = 4096 + h->npad;
     if (ext) {
         h->external_factor = true;
         h->L = ext->L;
@@ -466,9 +467,9 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
             }
         }
     }
-    // alpha = L^-T (L^-1 t)
-    if ((rc = trsv_forward(h->L, h->npad, h->Dinv, h->nblk, h->t, h->y, h->small + 4096, s, &h->prof))) return fail(rc);
-    if ((rc = trsv_backward(h->L, h->npad, h->Dinv, h->nblk, h->y, h->alpha, h->small + 4096, s, &h->prof))) return fail(rc);
+    // y = L^-1 t, alpha = L^-T y: the solver's diagonal-square inverses are kept for the propagation right after a fit
+    if ((rc = h->tri.prepare(h->L, h->npad, h->nblk, h->Dinv, s, &h->prof))) return fail(rc);
+    if ((rc = h->tri.solve(h->t, h->npad, 1, h->y, h->alpha, s, &h->prof))) return fail(rc);
     FIT_HIP(hipStreamSynchronize(s));
 #undef FIT_HIP
     *out = h;
@@ -580,6 +581,68 @@ extern "C" int gpx_alpha(gpx_handle *h, double *beta_out)
     return 0;
 }
 
+// K^-1 B (and L^-1 B) for a few right-hand sides without K^-1: two sweeps over the triangle of L per 32 right-hand sides
+extern "C" int gpx_solve(gpx_handle *h, const double *B, int nrhs, double *Linv_B_out, double *Kinv_B_out)
+{
+    CHECK_H(h);
+    if (!B || nrhs < 1 || (!Linv_B_out && !Kinv_B_out)) { gpx_set_error("gpx_solve: bad arguments (nrhs=%d)", nrhs); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    double *buf = nullptr;   // [3][32][npad]: zero-padded right-hand sides, L^-1 B, K^-1 B
+    GPX_TRY(dalloc(&buf, 3 * 32 * h->npad));
+    auto body = [&]() -> int {
+        double *b = buf, *y = buf + 32 * h->npad, *a = y + 32 * h->npad;
+        for (int c0 = 0; c0 < nrhs; c0 += 32) {
+            const int nc = std::min(32, nrhs - c0);
+            GPX_HIP(hipMemsetAsync(b, 0, sizeof(double) * 32 * h->npad, s));
+            GPX_HIP(hipMemcpy2DAsync(b, sizeof(double) * h->npad, B + (int64_t)c0 * h->n, sizeof(double) * h->n, sizeof(double) * h->n, nc,
+                                     hipMemcpyDefault, s));
+            GPX_TRY(h->tri.solve(b, h->npad, nc, Linv_B_out ? y : nullptr, Kinv_B_out ? a : nullptr, s, &h->prof));
+            if (Linv_B_out)
+                GPX_HIP(hipMemcpy2DAsync(Linv_B_out + (int64_t)c0 * h->n, sizeof(double) * h->n, y, sizeof(double) * h->npad,
+                                         sizeof(double) * h->n, nc, hipMemcpyDefault, s));
+            if (Kinv_B_out)
+                GPX_HIP(hipMemcpy2DAsync(Kinv_B_out + (int64_t)c0 * h->n, sizeof(double) * h->n, a, sizeof(double) * h->npad,
+                                         sizeof(double) * h->n, nc, hipMemcpyDefault, s));
+        }
+        return 0;
+    };
+    const int rc = body();
+    const hipError_t e = hipStreamSynchronize(s);
+    dfree(buf);
+    GPX_TRY(rc);
+    GPX_HIP(e);
+    return 0;
+}
+
+// L Z for a few vectors (rows of Z): a draw t = L z ~ N(0, K) for every standard-normal row z
+extern "C" int gpx_chol_mul(gpx_handle *h, const double *Z, int nrhs, double *out)
+{
+    CHECK_H(h);
+    if (!Z || !out || nrhs < 1) { gpx_set_error("gpx_chol_mul: bad arguments (nrhs=%d)", nrhs); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    double *buf = nullptr;   // [2][32][npad]
+    GPX_TRY(dalloc(&buf, 2 * 32 * h->npad));
+    auto body = [&]() -> int {
+        double *b = buf, *o = buf + 32 * h->npad;
+        for (int c0 = 0; c0 < nrhs; c0 += 32) {
+            const int nc = std::min(32, nrhs - c0);
+            GPX_HIP(hipMemsetAsync(b, 0, sizeof(double) * 32 * h->npad, s));
+            GPX_HIP(hipMemcpy2DAsync(b, sizeof(double) * h->npad, Z + (int64_t)c0 * h->n, sizeof(double) * h->n, sizeof(double) * h->n, nc,
+                                     hipMemcpyDefault, s));
+            GPX_TRY(h->tri.mul_lower(b, h->npad, nc, o, s));
+            GPX_HIP(hipMemcpy2DAsync(out + (int64_t)c0 * h->n, sizeof(double) * h->n, o, sizeof(double) * h->npad, sizeof(double) * h->n, nc,
+                                     hipMemcpyDefault, s));
+        }
+        return 0;
+    };
+    const int rc = body();
+    const hipError_t e = hipStreamSynchronize(s);
+    dfree(buf);
+    GPX_TRY(rc);
+    GPX_HIP(e);
+    return 0;
+}
+
 static int ensure_kinv(gpx_handle *h)
 {
     if (h->Kinv) return 0;
@@ -685,16 +748,11 @@ static int prepare_u(gpx_handle *h, const double *u)
     GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
     GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
     if (by_solves) {
-        // KV = V K^-1 row by row: K^-1 v = L^-T (L^-1 v) as two streaming multi-right-hand-side triangular solves
+        // KV = V K^-1 row by row: K^-1 v = L^-T (L^-1 v) as two sweeps of the few-right-hand-side triangular solver
         // (tsolve.hip) that read the triangle of L once each -- no K^-1, no transposed copy of the factor
-        double *ws = h->small + 4096, *ws2 = ws + 32 * h->npad;
         const int nrhs = h->d + 1;
-        for (int c0 = 0; c0 < nrhs; c0 += 32) {
-            const int ng = (nrhs - c0 > 16) ? 2 : 1;
-            GPX_HIP(hipMemcpyAsync(ws, h->V + (int64_t)c0 * h->npad, sizeof(double) * 16 * ng * h->npad, hipMemcpyDeviceToDevice, s));
-            GPX_TRY(tsolve_forward(h->L, h->npad, h->Dinv, h->nblk, ws, ws2, h->npad, ng, s, &h->prof));
-            GPX_TRY(tsolve_backward(h->L, h->npad, h->Dinv, h->nblk, ws2, h->KV + (int64_t)c0 * h->npad, h->npad, ng, s, &h->prof));
-        }
+        for (int c0 = 0; c0 < nrhs; c0 += 32)
+            GPX_TRY(h->tri.solve(h->V + (int64_t)c0 * h->npad, h->npad, std::min(32, nrhs - c0), nullptr, h->KV + (int64_t)c0 * h->npad, s, &h->prof));
         ++h->approx_solves;
     } else {
         // KV = V Kinv^T (= V Kinv): rows 0..d are Kinv C, Kinv J_k -- the ONE pass over Kinv shared by K2..K6

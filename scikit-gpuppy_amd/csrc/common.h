@@ -55,6 +55,23 @@ struct ProfScope {
     ~ProfScope() { if (idx >= 0) p->end(s, idx); }
 };
 
+// ---- triangular solves with a few right-hand sides against a factor (tsolve.hip) -----------------
+// prepare() inverts the 1024 x 1024 diagonal squares of the factor once (from the 128-block inverses Dinv); solve() then
+// runs N / 1024 fat steps per sweep.  The solver borrows L and Dinv: they must outlive it.
+struct TriSolver {
+    const double *L = nullptr, *Dinv = nullptr;
+    int64_t ld = 0, nblk = 0, npad = 0, P = 0;
+    double *Pl = nullptr, *Pz = nullptr;   // [P][1024][1024] inverses of the diagonal squares and their transposes
+    double *T = nullptr;                   // [P][512][512] scratch of the doubling levels
+    double *W = nullptr, *Y = nullptr;     // [32 npad] right-hand sides / solutions in the pair-major layout
+    int prepare(const double *L, int64_t ld, int64_t nblk, const double *Dinv, hipStream_t s, Profiler *prof);
+    // B [nrhs][ldb] (right-hand sides as rows, nrhs <= 32) -> Yout = L^-1 B and / or Aout = L^-T L^-1 B (null = skip)
+    int solve(const double *B, int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof);
+    int mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hipStream_t s);   // OUT = L B (rows, nrhs <= 32)
+    void release();
+    bool ready() const { return Pl != nullptr; }
+};
+
 // ---- the fitted model held in HBM ------------------------------------------------------------
 struct gpx_handle {
     int device = 0;
@@ -79,6 +96,7 @@ struct gpx_handle {
     double *t = nullptr;        // [npad] centred targets (zero padded)
     double *y = nullptr;        // [npad] L^-1 t
     double *alpha = nullptr;    // [npad] K^-1 t
+    TriSolver tri;              // few-right-hand-side solves against L (alpha, the propagation right after a fit)
     double *Kinv = nullptr;     // [npad, npad] lazily materialised
     int *info_dev = nullptr;    // [0] potrf info (1-based failing column, 0 = ok)
     double logdet = 0;
@@ -107,6 +125,12 @@ int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const dou
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
                    hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0);
+// batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
+// tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
+enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3 };
+struct GemmBatch { int nq; long sp, sq; int tri; };
+int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
+                           GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof);
 
@@ -120,16 +144,6 @@ int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
-// streaming multi-right-hand-side triangular solves (tsolve.hip); W [16 ng][npad] is destroyed, ng = 1 or 2
-int tsolve_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *Y, int64_t npad, int ng,
-                   hipStream_t s, Profiler *prof);
-int tsolve_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *A, int64_t npad, int ng,
-                    hipStream_t s, Profiler *prof);
-// single right-hand side: scratch holds 32 x (nblk * 128) doubles
-int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y,
-                 double *scratch, hipStream_t s, Profiler *prof);
-int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a,
-                  double *scratch, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
 int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
                           double *mean, double *var, hipStream_t s, Profiler *prof);

@@ -28,8 +28,15 @@ __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 template <int WM, int WN, bool LOWER>
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
-                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows)
+                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
+                                                            GemmBatch ba, GemmBatch bb, GemmBatch bc)
 {
+    if (ba.nq) {   // batched launch: problem blockIdx.z = (p, q), operands at base + p * sp + q * sq
+        const int z = blockIdx.z, p = z / ba.nq, q = z - p * ba.nq;
+        A += p * ba.sp + q * ba.sq;
+        B += p * bb.sp + q * bb.sq;
+        C += p * bc.sp + q * bc.sq;
+    }
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
     // ONE LDS array: per stage an A image [BTM][16] and a B image [BTN][16] of doubles (128-byte rows, no padding),
@@ -89,6 +96,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         }
     }
 
+    if (ba.nq) {
+        // batched launches with a triangular operand: tile lengths depend on by (or bx), and the dispatcher hands tile
+        // (by, bx) of every problem to the same CU / XCD -- rotate the tile coordinates with the problem index so that
+        // every CU sees the whole mix of lengths
+        by = (by + (int)blockIdx.z) % (int)gridDim.y;
+        bx = (bx + (int)blockIdx.z) % (int)gridDim.x;
+    }
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -105,11 +119,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
     // k = max(0, by * BTM - (ktrim - 1)).
     long kstart = 0;
+    int kend = K;
     if (ktrim) {
         kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
         if (kstart < 0) kstart = 0;
         if (kstart > K) kstart = K;
     }
+    // batched launches (square problems, M = N = K): one triangular operand, GemmBatch::tri of the A descriptor
+    if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
+    else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
+    else if (ba.tri == GEMM_TRI_B_LOWER) kend = min(K, (bx + 1) * BTN);            // B[j][k] = 0 for k > j
     const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda + kstart);
     const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb + kstart);
     unsigned aoff[(BTM / 8 + 3) / 4], boff[(BTN / 8 + 3) / 4];
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         }                                                                                                           \
     }
 
-    const int nk = (K - (int)kstart) / GEMM_BK;
+    const int nk = (kend - (int)kstart) / GEMM_BK;
     GPX_DMA_STAGE(0, 0)
     // C enters through the accumulators: acc0 = (beta/alpha) C, result = alpha (acc0 + A B^T).  The tile's read
     // overlaps the first DMA stage instead of sitting, dependent, in the epilogue (matters for the K = 128..512
@@ -288,16 +307,17 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: in-place product needs N == %d", TILE);
         return GPX_ERR_BAD_ARG;
     }
+    const GemmBatch nb_ = {0, 0, 0, 0};
 #define GPX_LAUNCH(WM_, WN_)                                                                                          \
     do {                                                                                                              \
         dim3 grid((unsigned)(N / (32 * WN_)), (unsigned)(M / (32 * WM_)));                                            \
         const unsigned nt_ = (unsigned)(M / (32 * WM_)), off_ = (unsigned)(trap / (32 * WN_));                        \
         if (lower_only)                                                                                               \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2 + off_ * nt_), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, (int)off_, ktrim, (int)nt_);                                  \
+                               (long)ldc, (int)K, alpha, beta, (int)off_, ktrim, (int)nt_, nb_, nb_, nb_);                   \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, 0, ktrim, 0);                                                 \
+                               (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, nb_, nb_, nb_);                                  \
     } while (0)
     if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
@@ -306,6 +326,24 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         else GPX_LAUNCH(1, 4);
     } else GPX_LAUNCH(2, 2);
 #undef GPX_LAUNCH
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// batch of independent products C_z = alpha A_z B_z^T + beta C_z, z = (p, q): operand z sits at base + p * sp + q * sq
+// (GemmBatch per operand; nq = number of q per p).  Small problems (the recursive doubling of the diagonal-square
+// inverses, tsolve.hip): 64 x 64 block tiles, one grid z-slice per problem.
+int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
+                           GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s)
+{
+    if (M % 64 || N % 64 || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0 ||
+        ba.nq < 1 || bb.nq != ba.nq || bc.nq != ba.nq || batch < 1 || batch > 65535 || ((ba.sp | ba.sq | bb.sp | bb.sq) & 1)) {
+        gpx_set_error("launch_gemm_nt_batched: shape/alignment not supported (M=%ld N=%ld K=%ld batch=%ld)", (long)M, (long)N, (long)K, (long)batch);
+        return GPX_ERR_BAD_ARG;
+    }
+    dim3 grid((unsigned)(N / 64), (unsigned)(M / 64), (unsigned)batch);
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<2, 2, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta, 0,
+                       0, 0, ba, bb, bc);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -32,7 +32,7 @@ struct gpx_spgp {
     double *lam = nullptr;   // [npad] lambda_n
     double *ilam = nullptr;  // [npad] 1/sqrt(lambda_n), 0 in the padding
     double *va = nullptr, *vb = nullptr, *vc = nullptr;         // [npad] vector scratch
-    double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad] ([32 mpad] for mscr)
+    double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad]
     double *outd = nullptr;  // [8] scalar results
     int *info = nullptr;
     static constexpr int SPLIT = 8;                 // K-chunks of the tall-skinny product W^T W (K = N)
@@ -228,7 +228,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(dalloc(&h->LM, mp * mp)); GPX_TRY(dalloc(&h->DinvM, tt)); GPX_TRY(dalloc(&h->diagM, mp));
     GPX_TRY(dalloc(&h->LB, mp * mp)); GPX_TRY(dalloc(&h->DinvB, tt)); GPX_TRY(dalloc(&h->diagB, mp));
     GPX_TRY(dalloc(&h->lam, np)); GPX_TRY(dalloc(&h->ilam, np)); GPX_TRY(dalloc(&h->va, np)); GPX_TRY(dalloc(&h->vb, np)); GPX_TRY(dalloc(&h->vc, np));
-    GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, 32 * mp));   // tsolve workspace: residual + output, 16 rows each
+    GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
     GPX_TRY(dalloc(&h->outd, 8));
     {
         double *ib = nullptr;
@@ -275,9 +275,13 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     // r = K_MN Lambda^-1 t = W^T (Lambda^-1/2 t) ;  beta = B~^-1 r             (commented estimate, :781-784)
     GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->ilam, h->va, nullptr, s));
     GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->va, 0.0, h->ma, h->mb, s, nullptr));
-    GPX_TRY(trsv_forward(h->LB, mp, h->DinvB, h->mblk, h->ma, h->mb, h->mscr, s, nullptr));
-    GPX_TRY(trsv_backward(h->LB, mp, h->DinvB, h->mblk, h->mb, h->beta, h->mscr, s, nullptr));
-    GPX_HIP(hipStreamSynchronize(s));
+    TriSolver ts;
+    int rt = ts.prepare(h->LB, mp, h->mblk, h->DinvB, s, nullptr);
+    if (!rt) rt = ts.solve(h->ma, mp, 1, h->mb, h->beta, s, nullptr);
+    const hipError_t es = hipStreamSynchronize(s);
+    ts.release();
+    GPX_TRY(rt);
+    GPX_HIP(es);
     return 0;
 }
 
@@ -353,6 +357,7 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
     double *L = nullptr, *Dinv = nullptr, *diag = nullptr, *A = nullptr, *DinvA = nullptr, *diagA = nullptr;
     int info = 0;
     double o[4] = {0, 0, 0, 0};
+    TriSolver ts;
     auto body = [&]() -> int {
         GPX_TRY(dalloc(&L, mp * mp)); GPX_TRY(dalloc(&Dinv, tt)); GPX_TRY(dalloc(&diag, mp));
         GPX_TRY(dalloc(&A, mp * mp)); GPX_TRY(dalloc(&DinvA, tt)); GPX_TRY(dalloc(&diagA, mp));
@@ -368,7 +373,8 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
         GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
         GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));  // Lm
         GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V y
-        GPX_TRY(trsv_forward(A, mp, DinvA, h->mblk, h->ma, h->mb, h->mscr, s, nullptr));            // bet = Lm^-1 V y
+        GPX_TRY(ts.prepare(A, mp, h->mblk, DinvA, s, nullptr));
+        GPX_TRY(ts.solve(h->ma, mp, 1, h->mb, nullptr, s, nullptr));                                // bet = Lm^-1 V y
         std::vector<std::pair<const double *, const double *>> pr;
         pr.push_back({h->vb, h->vb});
         GPX_TRY(launch_dot_pairs(pr, np, h->outd, s));                                              // y^T y
@@ -384,6 +390,7 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
     };
     const int rc = body();
     (void)hipStreamSynchronize(s);
+    ts.release();
     dfree(L); dfree(Dinv); dfree(diag); dfree(A); dfree(DinvA); dfree(diagA);
     if (rc) return rc;
     // fw = sum log diag(Lm) + (N-M)/2 log vt + (y^T y - bet^T bet)/(2 vt) + sum log(ep)/2 + N/2 log 2 pi   (:1017)

@@ -1,395 +1,355 @@
-// tsolve.hip -- streaming multi-right-hand-side triangular solves against the Cholesky factor, gfx950.
+// tsolve.hip -- triangular solves with a few right-hand sides against the Cholesky factor, gfx950.
 //
-//   forward :  Y = L^-1  B        backward :  A = L^-T S        B, S, Y, A : up to 32 right-hand sides, stored as ROWS
-//                                                               [c][npad] (the layout of the propagation block V)
+//   Y = L^-1 B ,  A = L^-T Y = K^-1 B          B: up to 32 right-hand sides stored as ROWS [c][npad]
 //
 // Replaces, on the hot path, the reference's  Kinv . t  (skgpuppy/GaussianProcess.py:114-119, beta = K^-1 t) and the
 // quadratic forms  v^T Kinv v  of the Approx propagation right after a fit (skgpuppy/UncertaintyPropagation.py:412-481:
-// K^-1 [C, J_1..J_d] = L^-T L^-1 [..] without ever forming K^-1).  Both directions read the triangle of L exactly once
-// (4 N^2 bytes): HBM-bound, plus one dependent step per STEP_BLOCKS x 128 rows.
+// K^-1 [C, J_1..J_d] = L^-T L^-1 [..] without ever forming K^-1).
 //
-// One launch per step of STEP_BLOCKS diagonal blocks.  Every workgroup first solves the step's diagonal block system
-// redundantly in LDS (the chain of 128-blocks with the inverted diagonal blocks Dinv of the factorisation: products with
-// 128 x 128 tiles that all workgroups share through L2), then applies the step's solution to its own 32 rows (forward)
-// or 64 columns (backward) of the remaining system.  All products run on v_mfma_f64_16x16x4 with the A fragments loaded
-// straight from global memory (16 B per lane; the contraction index is permuted consistently between the A and B
-// fragments so that a lane's two consecutive doubles feed two MFMAs) -- no cross-lane reductions anywhere.
+// Both sweeps are HBM-bound on the triangle of L (4 N^2 bytes each) -- and latency-bound on the chain of dependent
+// diagonal blocks.  The chain is shortened to one link per 1024 rows: the 1024 x 1024 diagonal squares of L are inverted
+// once per factor (TriSolver::prepare: recursive doubling from the 128-block inverses the factorisation leaves behind,
+// three levels of batched MFMA GEMMs over all squares at once), so a sweep is P = N / 1024 steps of
+//     diagonal:  y_p = inv(L_pp) w_p                 (64 workgroups, 16 rows each)
+//     update  :  w[below] -= L[below, p] y_p         (one workgroup per 16 rows / 32 columns, streaming L once)
+// Every product runs on v_mfma_f64_16x16x4 with both operands loaded straight from global memory as 16-byte
+// fragments: the right-hand sides live in a "pair-major" layout  P(k, c) = buf[((k >> 1) * NC + c) * 2 + (k & 1)]
+// (NC = 16 or 32 columns), in which a lane's two consecutive k of the matrix operand meet two consecutive k of the
+// vector operand in one load.  No atomics; the partial sums of a workgroup's waves are added in a fixed order.
+#include <algorithm>
+
 #include "common.h"
 
-constexpr int TS_BLOCKS = 2;                 // diagonal 128-blocks per step (256 rows): measured sweet spot between the
-                                             // number of dependent launches and the redundant per-step block solve
-
-template <int NG> struct TsLds { static constexpr int LS = 16 * NG + 8; };   // LDS row stride (doubles): k-slots 2 rows apart land 128 B apart mod 256
+constexpr int PB = 1024;                     // rows per step = the factorisation's outer panel (CHOL_NBP tiles)
+constexpr int PBT = PB / TILE;
 
 #define TS_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-// Latency: a step is a chain of dependent 128 x 128 tile products (Dinv_0, L_10, Dinv_1 forward; Dinv_1, L_10^T, Dinv_0
-// backward).  None of the tile fragments depends on the right-hand sides, so every global load of a step is issued into
-// registers before the product that needs it (the diagonal tiles and the in-step tile at kernel entry, the workgroup's
-// own rows/columns while the first products run): the dependent chain then only waits on LDS and the MFMA pipe.
-static_assert(TS_BLOCKS == 2, "the step kernels below are written for two diagonal blocks per step");
+enum { TS_LOWER = 0, TS_UPPER = 1, TS_UPDATE = 2 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward step: blocks [b0, b0 + nb) ;  W = residual (rows >= b0*128 are current), Y = solution
+// OUT (+)= A X over rows: workgroup g owns rows [16 g, 16 g + 16) of A (row-major, lda; column 0 = first contraction
+// index), its 4 waves split the contraction range (batches of 8 fragments: < 128 VGPRs, so several workgroups share a CU
+// and one's loads overlap another's reduction).  X: pair-major, k = 0 at X.  OUT: pair-major, row 0 at OUT.
+//   TS_LOWER : A lower triangular, OUT  = A X   (contraction k < 16 (g + 1))
+//   TS_UPPER : A upper triangular, OUT  = A X   (contraction k >= 16 g)
+//   TS_UPDATE: A rectangular,      OUT -= A X
 // ------------------------------------------------------------------------------------------------------------------
-template <int NG>
-__global__ __launch_bounds__(256) void tsolve_fwd_step(const double *__restrict__ L, long ld, const double *__restrict__ Dinv,
-                                                      int b0, int nb, int nblk, double *W, double *__restrict__ Y, long npad)
+template <int NG, int MODE>
+__global__ __launch_bounds__(256) void ts_rows_kernel(const double *__restrict__ A, long lda, int K, const double *__restrict__ X,
+                                                     double *OUT)
 {
-    constexpr int NC = 16 * NG, LS = TsLds<NG>::LS;
-    __shared__ __attribute__((aligned(16))) double wl[TS_BLOCKS * TILE * LS];
-    __shared__ __attribute__((aligned(16))) double red[2][NG][256];
+    constexpr int NC = 16 * NG, NB = 8;
+    __shared__ double red[4][NG][4][64];
     const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, fr = lane & 15, fq = lane >> 4;
-    const long rowbase = (long)b0 * TILE;
-    const int rows = nb * TILE;
-    // Dinv (lower triangular): row group g contracts over k < 16 (g + 1) = 2 (g + 1) chunks of 8; wave w takes the groups
-    // gA = w and gB = 7 - w: 18 chunks for every wave.  Chunk slot i < cntA belongs to gA (chunk i), else to gB (chunk i - cntA).
-    const int gA = wave, gB = 7 - wave, cntA = 2 * (gA + 1);
-    auto dfrag = [&](int a, int i) -> const double * {
-        const int g = i < cntA ? gA : gB, kk = i < cntA ? i : i - cntA;
-        return Dinv + (long)(b0 + a) * TILE * TILE + (long)(16 * g + fr) * TILE + 2 * fq + 8 * kk;
-    };
-    v2d d0[18], d1[18], lf[2][16], pf[16];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) d0[i] = *reinterpret_cast<const v2d *>(dfrag(0, i));
-    if (nb == 2) {
-        // in-step tile L[b0+1][b0]: row groups wave and wave + 4
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const double *Ap = L + ((long)(b0 + 1) * TILE + 16 * (wave + 4 * q) + fr) * ld + rowbase + 2 * fq;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) lf[q][kk] = *reinterpret_cast<const v2d *>(Ap + 8 * kk);
-        }
-    }
-    for (int idx = t; idx < rows * NC; idx += 256) {
-        const int c = idx / rows, j = idx - c * rows;
-        wl[j * LS + c] = W[(long)c * npad + rowbase + j];
-    }
-    __syncthreads();
-
-    auto diag_stage = [&](int a, const v2d (&df)[18]) {
-        v4d accA[NG], accB[NG];
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng) { accA[ng] = (v4d){0.0, 0.0, 0.0, 0.0}; accB[ng] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-        const double *Bp = &wl[(a * TILE + 2 * fq) * LS + fr];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) {
-            const int kk = i < cntA ? i : i - cntA;
-            if (i < cntA) {
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) {
-                    accA[ng] = TS_MFMA(df[i].x, Bp[(8 * kk) * LS + 16 * ng], accA[ng]);
-                    accA[ng] = TS_MFMA(df[i].y, Bp[(8 * kk + 1) * LS + 16 * ng], accA[ng]);
-                }
-            } else {
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) {
-                    accB[ng] = TS_MFMA(df[i].x, Bp[(8 * kk) * LS + 16 * ng], accB[ng]);
-                    accB[ng] = TS_MFMA(df[i].y, Bp[(8 * kk + 1) * LS + 16 * ng], accB[ng]);
-                }
-            }
-        }
-        __syncthreads();   // every read of w_a is done
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                wl[(a * TILE + 16 * gA + fq + 4 * r) * LS + fr + 16 * ng] = accA[ng][r];
-                wl[(a * TILE + 16 * gB + fq + 4 * r) * LS + fr + 16 * ng] = accB[ng][r];
-            }
-        __syncthreads();
-    };
-
-    diag_stage(0, d0);
-    if (nb == 2) {
-#pragma unroll
-        for (int i = 0; i < 18; ++i) d1[i] = *reinterpret_cast<const v2d *>(dfrag(1, i));
-        // w_1 -= L[b0+1][b0] y_0
-        const double *Bp = &wl[(2 * fq) * LS + fr];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            v4d acc[NG];
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[ng] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) {
-                    acc[ng] = TS_MFMA(lf[q][kk].x, Bp[(8 * kk) * LS + 16 * ng], acc[ng]);
-                    acc[ng] = TS_MFMA(lf[q][kk].y, Bp[(8 * kk + 1) * LS + 16 * ng], acc[ng]);
-                }
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wl[(TILE + 16 * (wave + 4 * q) + fq + 4 * r) * LS + fr + 16 * ng] -= acc[ng][r];
-        }
-    }
-    // this workgroup's 32 rows below the step (row group rg of 16, half kh of the contraction): fragments on their way
-    // while the last diagonal product runs
-    const long rb = rowbase + rows + 32L * blockIdx.x;
-    const bool has_rows = rb < (long)nblk * TILE;
-    const int rg = wave & 1, kh = wave >> 1, khalf = rows / 2;
-    const int nchunk = khalf / 8;                         // 8 or 16
-    if (has_rows) {
-        const double *Ap = L + (rb + 16 * rg + fr) * ld + rowbase + kh * khalf + 2 * fq;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (u < nchunk) pf[u] = *reinterpret_cast<const v2d *>(Ap + 8 * u);
-    }
-    if (nb == 2) {
-        __syncthreads();
-        diag_stage(1, d1);
-    }
-    if (blockIdx.x == 0)
-        for (int idx = t; idx < rows * NC; idx += 256) {
-            const int c = idx / rows, j = idx - c * rows;
-            Y[(long)c * npad + rowbase + j] = wl[j * LS + c];
-        }
-    if (!has_rows) return;
+    const int g = blockIdx.x;
+    int klo = 0, khi = K;
+    if (MODE == TS_LOWER) khi = min(K, 16 * (g + 1));
+    if (MODE == TS_UPPER) klo = 16 * g;
+    // chunks of 8 contraction indices: a lane's 16-byte fragment holds k = 8 ch + 2 fq, + 1 -> two MFMAs
+    const int c0 = klo >> 3, c1 = khi >> 3;
+    const int cpw = (c1 - c0 + 3) >> 2;
+    const int cb = c0 + wave * cpw, ce = min(c1, cb + cpw);
+    const double *Ap = A + (long)(16 * g + fr) * lda + 2 * fq;
+    const double *Xp = X + (long)(fq * NC + fr) * 2;        // pair index of k = 8 ch + 2 fq is 4 ch + fq
     v4d acc[NG];
 #pragma unroll
     for (int ng = 0; ng < NG; ++ng) acc[ng] = (v4d){0.0, 0.0, 0.0, 0.0};
-    {
-        const double *Bp = &wl[(kh * khalf + 2 * fq) * LS + fr];
+    for (int ch = cb; ch < ce; ch += NB) {
+        v2d a[NB], b[NG][NB];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-            if (u < nchunk) {
+        for (int u = 0; u < NB; ++u)
+            if (ch + u < ce) {
+                a[u] = *reinterpret_cast<const v2d *>(Ap + 8 * (ch + u));
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) b[ng][u] = *reinterpret_cast<const v2d *>(Xp + ((long)(4 * (ch + u)) * NC + 16 * ng) * 2);
+            }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (ch + u < ce) {
 #pragma unroll
                 for (int ng = 0; ng < NG; ++ng) {
-                    acc[ng] = TS_MFMA(pf[u].x, Bp[(8 * u) * LS + 16 * ng], acc[ng]);
-                    acc[ng] = TS_MFMA(pf[u].y, Bp[(8 * u + 1) * LS + 16 * ng], acc[ng]);
+                    acc[ng] = TS_MFMA(a[u].x, b[ng][u].x, acc[ng]);
+                    acc[ng] = TS_MFMA(a[u].y, b[ng][u].y, acc[ng]);
                 }
             }
     }
-    if (kh == 1)
 #pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
+    for (int ng = 0; ng < NG; ++ng)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[rg][ng][r * 64 + lane] = acc[ng][r];
+        for (int r = 0; r < 4; ++r) red[wave][ng][r][lane] = acc[ng][r];
     __syncthreads();
-    if (kh == 0)
+    if (wave < NG) {
+        const int ng = wave;
 #pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
+        for (int r = 0; r < 4; ++r) {
+            double s = red[0][ng][r][lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double *wp = W + (long)(fr + 16 * ng) * npad + rb + 16 * rg + fq + 4 * r;
-                *wp -= acc[ng][r] + red[rg][ng][r * 64 + lane];
-            }
+            for (int w = 1; w < 4; ++w) s += red[w][ng][r][lane];
+            const long row = 16L * g + fq + 4 * r;             // accumulator register r is row fq + 4 r, column fr
+            double *o = OUT + ((row >> 1) * NC + 16 * ng + fr) * 2 + (row & 1);
+            if (MODE == TS_UPDATE) *o -= s;
+            else *o = s;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// backward step: blocks [b0, b0 + nb), steps run from the last block to the first;  W = residual, A = solution
-//   a_step = L_step^-T s_step ;  s[cols < b0*128] -= L[step rows, cols]^T a_step
+// backward update: S[j] -= sum_i Lp[i][j] a[i] over the K rows of a panel; workgroup b owns columns [32 b, 32 b + 32),
+// its 8 waves split the rows.  Lp: first row of the panel, column 0.  Apm: pair-major, i = 0 at Apm.  S: pair-major.
+// A lane's 16-byte fragment holds the two adjacent columns 2 fr, 2 fr + 1 of row 4 u + fq: two MFMAs share one vector value.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NG>
-__global__ __launch_bounds__(256) void tsolve_bwd_step(const double *__restrict__ L, long ld, const double *__restrict__ Dinv,
-                                                      int b0, int nb, double *W, double *__restrict__ A, long npad)
+__global__ __launch_bounds__(512) void ts_cols_kernel(const double *__restrict__ Lp, long ld, int K, const double *__restrict__ Apm,
+                                                     double *S)
 {
-    constexpr int NC = 16 * NG, LS = TsLds<NG>::LS;
-    __shared__ __attribute__((aligned(16))) double wl[TS_BLOCKS * TILE * LS];
-    __shared__ __attribute__((aligned(16))) double red[2][2][NG][256];
+    constexpr int NC = 16 * NG, NB = 8;
+    __shared__ double red[8][2][NG][4][64];
     const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, fr = lane & 15, fq = lane >> 4;
-    const long rowbase = (long)b0 * TILE;
-    const int rows = nb * TILE;
-    // Dinv^T (upper triangular): column group g of 16 contracts over rows i >= 16 g = 32 - 4 g slots of 4 rows; wave w takes
-    // the groups gA = w and gB = 7 - w: 36 slots for every wave.  A[m = fr][k = fq] = Dinv[16 g + 4 s + fq][16 g' ...]
-    const int gA = wave, gB = 7 - wave, cntA = 32 - 4 * gA;
-    auto dfrag = [&](int a, int i) -> const double * {
-        const int g = i < cntA ? gA : gB, sl = i < cntA ? i : i - cntA;
-        return Dinv + (long)(b0 + a) * TILE * TILE + (long)(16 * g + 4 * sl + fq) * TILE + 16 * g + fr;
-    };
-    double dA[36], dB[36];
-    v2d lf[32], pf[32];
-    const int alast = nb - 1;
-#pragma unroll
-    for (int i = 0; i < 36; ++i) dA[i] = *dfrag(alast, i);
-    if (nb == 2) {
-        // in-step tile L[b0+1][b0] transposed: 32-column group mg = wave; lane (fr, fq) holds L[row 4 s + fq][col 32 mg + 2 fr + e]
-        const double *Ap = L + ((long)(b0 + 1) * TILE + fq) * ld + rowbase + 32 * wave + 2 * fr;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) lf[u] = *reinterpret_cast<const v2d *>(Ap + (long)(4 * u) * ld);
-    }
-    for (int idx = t; idx < rows * NC; idx += 256) {
-        const int c = idx / rows, j = idx - c * rows;
-        wl[j * LS + c] = W[(long)c * npad + rowbase + j];
-    }
-    __syncthreads();
-
-    auto diag_stage = [&](int a, const double (&df)[36]) {
-        v4d accA[NG], accB[NG];
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng) { accA[ng] = (v4d){0.0, 0.0, 0.0, 0.0}; accB[ng] = (v4d){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll
-        for (int i = 0; i < 36; ++i) {
-            const int g = i < cntA ? gA : gB, sl = i < cntA ? i : i - cntA;
-            const double *Bp = &wl[(a * TILE + 16 * g + 4 * sl + fq) * LS + fr];
-            if (i < cntA) {
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) accA[ng] = TS_MFMA(df[i], Bp[16 * ng], accA[ng]);
-            } else {
-#pragma unroll
-                for (int ng = 0; ng < NG; ++ng) accB[ng] = TS_MFMA(df[i], Bp[16 * ng], accB[ng]);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                wl[(a * TILE + 16 * gA + fq + 4 * r) * LS + fr + 16 * ng] = accA[ng][r];
-                wl[(a * TILE + 16 * gB + fq + 4 * r) * LS + fr + 16 * ng] = accB[ng][r];
-            }
-        __syncthreads();
-    };
-
-    diag_stage(alast, dA);
-    if (nb == 2) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) dB[i] = *dfrag(0, i);
-        // s_0 -= L[b0+1][b0]^T a_1 for this wave's 32 columns (two interleaved 16-column groups)
-        v4d acc[2][NG];
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) acc[e][ng] = (v4d){0.0, 0.0, 0.0, 0.0};
-        const double *Bp = &wl[(TILE + fq) * LS + fr];
-#pragma unroll
-        for (int u = 0; u < 32; ++u)
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng) {
-                const double bv = Bp[(4 * u) * LS + 16 * ng];
-                acc[0][ng] = TS_MFMA(lf[u].x, bv, acc[0][ng]);
-                acc[1][ng] = TS_MFMA(lf[u].y, bv, acc[1][ng]);
-            }
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) wl[(32 * wave + 2 * (fq + 4 * r) + e) * LS + fr + 16 * ng] -= acc[e][ng][r];
-    }
-    // this workgroup's 64 columns left of the step (32-column group mg, half kh of the step's rows)
-    const long cb = 64L * blockIdx.x;
-    const bool has_cols = cb < rowbase;
-    const int mg = wave & 1, kh = wave >> 1, khalf = rows / 2;
-    const int nslot = khalf / 4;                          // 16 or 32
-    if (has_cols) {
-        const double *Ap = L + (rowbase + kh * khalf + fq) * ld + cb + 32 * mg + 2 * fr;
-#pragma unroll
-        for (int u = 0; u < 32; ++u)
-            if (u < nslot) pf[u] = *reinterpret_cast<const v2d *>(Ap + (long)(4 * u) * ld);
-    }
-    if (nb == 2) {
-        __syncthreads();
-        diag_stage(0, dB);
-    }
-    if (blockIdx.x == 0)
-        for (int idx = t; idx < rows * NC; idx += 256) {
-            const int c = idx / rows, j = idx - c * rows;
-            A[(long)c * npad + rowbase + j] = wl[j * LS + c];
-        }
-    if (!has_cols) return;
+    const int b = blockIdx.x;
+    const int rpw = K >> 3;                                  // rows per wave (multiple of 16)
+    const int nst = rpw >> 2;                                // steps of 4 rows
+    const long i0 = (long)wave * rpw + fq;
+    const double *Ap = Lp + i0 * ld + 32L * b + 2 * fr;
     v4d acc[2][NG];
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
         for (int ng = 0; ng < NG; ++ng) acc[e][ng] = (v4d){0.0, 0.0, 0.0, 0.0};
-    {
-        const double *Bp = &wl[(kh * khalf + fq) * LS + fr];
+    for (int u0 = 0; u0 < nst; u0 += NB) {
+        v2d a[NB];
+        double bv[NG][NB];
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
-            if (u < nslot) {
+        for (int u = 0; u < NB; ++u)
+            if (u0 + u < nst) {
+                a[u] = *reinterpret_cast<const v2d *>(Ap + (long)(4 * (u0 + u)) * ld);
+                const long i = i0 + 4 * (u0 + u);
+#pragma unroll
+                for (int ng = 0; ng < NG; ++ng) bv[ng][u] = Apm[((i >> 1) * NC + 16 * ng + fr) * 2 + (i & 1)];
+            }
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
+            if (u0 + u < nst) {
 #pragma unroll
                 for (int ng = 0; ng < NG; ++ng) {
-                    const double bv = Bp[(4 * u) * LS + 16 * ng];
-                    acc[0][ng] = TS_MFMA(pf[u].x, bv, acc[0][ng]);
-                    acc[1][ng] = TS_MFMA(pf[u].y, bv, acc[1][ng]);
+                    acc[0][ng] = TS_MFMA(a[u].x, bv[ng][u], acc[0][ng]);
+                    acc[1][ng] = TS_MFMA(a[u].y, bv[ng][u], acc[1][ng]);
                 }
             }
     }
-    if (kh == 1)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-            for (int ng = 0; ng < NG; ++ng)
+        for (int ng = 0; ng < NG; ++ng)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[mg][e][ng][r * 64 + lane] = acc[e][ng][r];
+            for (int r = 0; r < 4; ++r) red[wave][e][ng][r][lane] = acc[e][ng][r];
     __syncthreads();
-    if (kh == 0)
+    if (wave < 2 * NG) {
+        const int e = wave & 1, ng = wave >> 1;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int r = 0; r < 4; ++r) {
+            double s = red[0][e][ng][r][lane];
 #pragma unroll
-            for (int ng = 0; ng < NG; ++ng)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double *wp = W + (long)(fr + 16 * ng) * npad + cb + 32 * mg + 2 * (fq + 4 * r) + e;
-                    *wp -= acc[e][ng][r] + red[mg][e][ng][r * 64 + lane];
-                }
+            for (int w = 1; w < 8; ++w) s += red[w][e][ng][r][lane];
+            const long m = fq + 4 * r;                           // column 32 b + 2 m + e: pair index 16 b + m, parity e
+            S[((16L * b + m) * NC + 16 * ng + fr) * 2 + e] -= s;
+        }
+    }
+}
+
+// rows [c][ldb] -> pair-major (columns >= nrhs are zero), and back for the first nrhs columns
+__global__ __launch_bounds__(256) void ts_pack_kernel(const double *__restrict__ B, long ldb, int nrhs, long npad, int NC, double *__restrict__ W)
+{
+    const long half = npad >> 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= half * NC) return;
+    const int c = (int)(idx / half);
+    const long pr = idx - (long)c * half;
+    v2d v = (v2d){0.0, 0.0};
+    if (c < nrhs) v = *reinterpret_cast<const v2d *>(B + (long)c * ldb + 2 * pr);
+    *reinterpret_cast<v2d *>(W + (pr * NC + c) * 2) = v;
+}
+
+__global__ __launch_bounds__(256) void ts_unpack_kernel(const double *__restrict__ W, long npad, int NC, int nrhs, double *__restrict__ B, long ldb)
+{
+    const long half = npad >> 1;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= half * nrhs) return;
+    const int c = (int)(idx / half);
+    const long pr = idx - (long)c * half;
+    *reinterpret_cast<v2d *>(B + (long)c * ldb + 2 * pr) = *reinterpret_cast<const v2d *>(W + (pr * NC + c) * 2);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// host side.  W: [16 ng][npad] residual (destroyed), OUT: [16 ng][npad]; ng = 1 or 2 column groups of 16 right-hand sides
+// inverses of the 1024 x 1024 diagonal squares.  Pl[p] <- inv(L_pp) (lower), Pz[p] <- inv(L_pp)^T (upper), both
+// [1024][1024] row-major.  The pack kernel seeds them with the 128-block inverses (and their transposes) on the
+// diagonal and the raw sub-diagonal tiles of L in Pl (the other triangle of either array is never written and never
+// read: the level GEMMs and the sweeps skip the zero part of a triangular operand); a square that reaches past the
+// factor (last panel) is completed by the identity.  Level h = 128, 256, 512 then joins pairs of inverted h-blocks:
+//     T^T = Z11 L21^T ,   inv21 = -inv22 T ,   Z12 = -T^T inv22^T        (three batched NT GEMMs, Z = inverse^T)
 // ------------------------------------------------------------------------------------------------------------------
-int tsolve_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *Y, int64_t npad, int ng,
-                   hipStream_t s, Profiler *prof)
+__global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__ L, long ld, long nblk, const double *__restrict__ Dinv,
+                                                     double *__restrict__ Pl, double *__restrict__ Pz)
 {
-    if (ng != 1 && ng != 2) { gpx_set_error("tsolve_forward: ng must be 1 or 2"); return GPX_ERR_BAD_ARG; }
-    ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)(nblk * TILE) * (double)(nblk * TILE));
-    for (int64_t b0 = 0; b0 < nblk; b0 += TS_BLOCKS) {
-        const int nb = (int)std::min<int64_t>(TS_BLOCKS, nblk - b0);
-        const int64_t below = (nblk - b0 - nb) * TILE;
-        const unsigned grid = (unsigned)std::max<int64_t>(1, below / 32);
-        if (ng == 1)
-            hipLaunchKernelGGL(tsolve_fwd_step<1>, dim3(grid), dim3(256), 0, s, L, (long)ld, Dinv, (int)b0, nb, (int)nblk, W, Y, (long)npad);
-        else
-            hipLaunchKernelGGL(tsolve_fwd_step<2>, dim3(grid), dim3(256), 0, s, L, (long)ld, Dinv, (int)b0, nb, (int)nblk, W, Y, (long)npad);
+    // blockIdx.x: [0, 28) sub-diagonal tiles (copy of L), [28, 36) diagonal tiles (copy of Dinv), [36, 68) transposed
+    // diagonal tiles, a 32-row strip each
+    __shared__ double tr[4][32][33];
+    const int bx = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
+    const int c2 = (t & 63) * 2, r4 = t >> 6;                 // 4 rows x 64 column pairs per pass
+    if (bx < 28) {
+        int ti = 1;
+        while ((ti + 1) * ti / 2 <= bx) ++ti;                  // row ti holds tiles tj < ti: indices ti (ti - 1) / 2 ...
+        const int tj = bx - ti * (ti - 1) / 2;
+        const long bi = (long)PBT * p + ti, bj = (long)PBT * p + tj;
+        const bool valid = bi < nblk;                          // (bj < bi)
+        const double *src = L + bi * TILE * ld + bj * TILE;
+        double *dl = Pl + (long)p * PB * PB + (long)ti * TILE * PB + tj * TILE;
+        for (int r = r4; r < TILE; r += 4) {
+            v2d v = (v2d){0.0, 0.0};
+            if (valid) v = *reinterpret_cast<const v2d *>(src + (long)r * ld + c2);
+            *reinterpret_cast<v2d *>(dl + (long)r * PB + c2) = v;
+        }
+        return;
+    }
+    const int ti = bx < 36 ? bx - 28 : (bx - 36) >> 2;
+    const long bi = (long)PBT * p + ti;
+    const bool valid = bi < nblk;
+    const double *src = Dinv + bi * (long)TILE * TILE;
+    const long doff = (long)p * PB * PB + (long)ti * TILE * PB + ti * TILE;
+    if (bx < 36) {
+        double *dl = Pl + doff;
+        for (int r = r4; r < TILE; r += 4) {
+            v2d v;
+            if (valid) v = *reinterpret_cast<const v2d *>(src + r * TILE + c2);
+            else { v.x = (c2 == r) ? 1.0 : 0.0; v.y = (c2 + 1 == r) ? 1.0 : 0.0; }
+            *reinterpret_cast<v2d *>(dl + (long)r * PB + c2) = v;
+        }
+        return;
+    }
+    // source rows [sr, sr + 32) -> destination columns [sr, sr + 32): four 32 x 32 LDS transposes at once
+    double *dz = Pz + doff;
+    const int sr = ((bx - 36) & 3) * 32;
+    const int tx = t & 31, ty = t >> 5;                        // 32 x 8
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = ty; r < 32; r += 8) tr[q][r][tx] = valid ? src[(sr + r) * TILE + 32 * q + tx] : ((sr + r == 32 * q + tx) ? 1.0 : 0.0);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        for (int r = ty; r < 32; r += 8) dz[(long)(32 * q + r) * PB + sr + tx] = tr[q][tx][r];
+}
+
+int TriSolver::prepare(const double *L_, int64_t ld_, int64_t nblk_, const double *Dinv_, hipStream_t s, Profiler *prof)
+{
+    release();
+    L = L_; ld = ld_; nblk = nblk_; Dinv = Dinv_;
+    npad = nblk * TILE;
+    P = (nblk + PBT - 1) / PBT;
+    int rc;
+    if ((rc = dalloc(&Pl, P * (int64_t)PB * PB)) || (rc = dalloc(&Pz, P * (int64_t)PB * PB)) || (rc = dalloc(&W, 32 * npad)) ||
+        (rc = dalloc(&Y, 32 * npad)) || (rc = dalloc(&T, P * (int64_t)(PB / 2) * (PB / 2)))) {
+        release();
+        return rc;
+    }
+    auto body = [&]() -> int {
+        ProfScope ps(prof, s, GPX_K_TRSV, 0.0);
+        hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)P), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, Pl, Pz);
+        GPX_HIP(hipGetLastError());
+        for (int64_t h = TILE; h < PB; h *= 2) {
+            const int64_t nq = PB / (2 * h);                  // pairs per square
+            GemmBatch ba, bb, bc;
+            const int64_t sp = (int64_t)PB * PB, sq = 2 * h * (PB + 1);
+            // T^T = Z11 L21^T
+            ba = {(int)nq, sp, sq, GEMM_TRI_A_UPPER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, nq * h * h, h * h, 0};
+            GPX_TRY(launch_gemm_nt_batched(Pz, PB, ba, Pl + h * PB, PB, bb, T, h, bc, h, h, h, 1.0, 0.0, P * nq, s));
+            // inv21 = -inv22 T   (over the slot that held L21)
+            ba = {(int)nq, sp, sq, GEMM_TRI_A_LOWER}; bb = {(int)nq, nq * h * h, h * h, 0}; bc = {(int)nq, sp, sq, 0};
+            GPX_TRY(launch_gemm_nt_batched(Pl + h * PB + h, PB, ba, T, h, bb, Pl + h * PB, PB, bc, h, h, h, -1.0, 0.0, P * nq, s));
+            // Z12 = -T^T inv22^T
+            ba = {(int)nq, nq * h * h, h * h, GEMM_TRI_B_LOWER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, sp, sq, 0};
+            GPX_TRY(launch_gemm_nt_batched(T, h, ba, Pl + h * PB + h, PB, bb, Pz + h, PB, bc, h, h, h, -1.0, 0.0, P * nq, s));
+        }
+        return 0;
+    };
+    rc = body();
+    if (rc) release();
+    return rc;
+}
+
+void TriSolver::release()
+{
+    if (Pl) dfree(Pl);
+    if (Pz) dfree(Pz);
+    if (W) dfree(W);
+    if (Y) dfree(Y);
+    if (T) dfree(T);
+    Pl = Pz = W = Y = T = nullptr;
+    L = Dinv = nullptr;
+    P = 0;
+}
+
+template <int NG>
+static int ts_sweeps(const TriSolver *ts, bool backward, hipStream_t s)
+{
+    constexpr int NC = 16 * NG;
+    const int64_t npad = ts->npad, ld = ts->ld;
+    if (!backward) {
+        for (int64_t p = 0; p < ts->P; ++p) {
+            const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0), below = npad - k0 - K;
+            hipLaunchKernelGGL((ts_rows_kernel<NG, TS_LOWER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pl + p * (int64_t)PB * PB, (long)PB,
+                               (int)K, ts->W + k0 * NC, ts->Y + k0 * NC);
+            if (below > 0)
+                hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPDATE>), dim3((unsigned)(below / 16)), dim3(256), 0, s, ts->L + (k0 + K) * ld + k0, (long)ld,
+                                   (int)K, ts->Y + k0 * NC, ts->W + (k0 + K) * NC);
+        }
+    } else {
+        // residual = Y (destroyed), solution -> W
+        for (int64_t p = ts->P - 1; p >= 0; --p) {
+            const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0);
+            hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPPER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pz + p * (int64_t)PB * PB, (long)PB,
+                               (int)K, ts->Y + k0 * NC, ts->W + k0 * NC);
+            if (k0 > 0)
+                hipLaunchKernelGGL((ts_cols_kernel<NG>), dim3((unsigned)(k0 / 32)), dim3(512), 0, s, ts->L + k0 * ld, (long)ld, (int)K,
+                                   ts->W + k0 * NC, ts->Y);
+        }
     }
     GPX_HIP(hipGetLastError());
     return 0;
 }
 
-int tsolve_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, double *W, double *A, int64_t npad, int ng,
-                    hipStream_t s, Profiler *prof)
+// B [nrhs][ldb] (rows) -> Yout = L^-1 B and/or Aout = L^-T L^-1 B, same layout (either may be null); nrhs <= 32
+int TriSolver::solve(const double *B, int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof)
 {
-    if (ng != 1 && ng != 2) { gpx_set_error("tsolve_backward: ng must be 1 or 2"); return GPX_ERR_BAD_ARG; }
-    ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)(nblk * TILE) * (double)(nblk * TILE));
-    // steps aligned like the forward ones: the last step takes the remainder
-    int64_t b1 = nblk;
-    while (b1 > 0) {
-        const int64_t b0 = (b1 - 1) / TS_BLOCKS * TS_BLOCKS;
-        const int nb = (int)(b1 - b0);
-        const unsigned grid = (unsigned)std::max<int64_t>(1, b0 * TILE / 64);
-        if (ng == 1)
-            hipLaunchKernelGGL(tsolve_bwd_step<1>, dim3(grid), dim3(256), 0, s, L, (long)ld, Dinv, (int)b0, nb, W, A, (long)npad);
-        else
-            hipLaunchKernelGGL(tsolve_bwd_step<2>, dim3(grid), dim3(256), 0, s, L, (long)ld, Dinv, (int)b0, nb, W, A, (long)npad);
-        b1 = b0;
+    if (!Pl || nrhs < 1 || nrhs > 32) { gpx_set_error("TriSolver::solve: not prepared or nrhs out of range (%d)", nrhs); return GPX_ERR_BAD_ARG; }
+    const int ng = nrhs > 16 ? 2 : 1, NC = 16 * ng;
+    const double tri_bytes = 4.0 * (double)npad * (double)npad;
+    ProfScope ps(prof, s, GPX_K_TRSV, tri_bytes * (Aout ? 2.0 : 1.0));
+    const unsigned gp = (unsigned)(((npad >> 1) * NC + 255) / 256);
+    hipLaunchKernelGGL(ts_pack_kernel, dim3(gp), dim3(256), 0, s, B, (long)ldb, nrhs, (long)npad, NC, W);
+    GPX_TRY(ng == 1 ? ts_sweeps<1>(this, false, s) : ts_sweeps<2>(this, false, s));
+    const unsigned gu = (unsigned)(((npad >> 1) * nrhs + 255) / 256);
+    if (Yout) hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)Y, (long)npad, NC, nrhs, Yout, (long)ldb);
+    if (Aout) {
+        GPX_TRY(ng == 1 ? ts_sweeps<1>(this, true, s) : ts_sweeps<2>(this, true, s));
+        hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)W, (long)npad, NC, nrhs, Aout, (long)ldb);
     }
     GPX_HIP(hipGetLastError());
     return 0;
 }
 
-// single right-hand side convenience (alpha = K^-1 t): b, y, a are [npad] vectors; scratch holds 2 x 16 x npad doubles
-int trsv_forward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *b, double *y, double *scratch,
-                 hipStream_t s, Profiler *prof)
+// OUT = L B for up to 32 vectors stored as rows (the sampling path t = L z: skgpuppy/GaussianProcess.py:44-57): one pass over
+// the triangle of L with the same row kernel
+int TriSolver::mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hipStream_t s)
 {
-    const int64_t npad = nblk * TILE;
-    double *W = scratch, *Yb = scratch + 16 * npad;
-    GPX_HIP(hipMemsetAsync(W, 0, sizeof(double) * 16 * npad, s));
-    GPX_HIP(hipMemcpyAsync(W, b, sizeof(double) * npad, hipMemcpyDeviceToDevice, s));
-    GPX_TRY(tsolve_forward(L, ld, Dinv, nblk, W, Yb, npad, 1, s, prof));
-    GPX_HIP(hipMemcpyAsync(y, Yb, sizeof(double) * npad, hipMemcpyDeviceToDevice, s));
-    return 0;
-}
-
-int trsv_backward(const double *L, int64_t ld, const double *Dinv, int64_t nblk, const double *y, double *a, double *scratch,
-                  hipStream_t s, Profiler *prof)
-{
-    const int64_t npad = nblk * TILE;
-    double *W = scratch, *Ab = scratch + 16 * npad;
-    GPX_HIP(hipMemsetAsync(W, 0, sizeof(double) * 16 * npad, s));
-    GPX_HIP(hipMemcpyAsync(W, y, sizeof(double) * npad, hipMemcpyDeviceToDevice, s));
-    GPX_TRY(tsolve_backward(L, ld, Dinv, nblk, W, Ab, npad, 1, s, prof));
-    GPX_HIP(hipMemcpyAsync(a, Ab, sizeof(double) * npad, hipMemcpyDeviceToDevice, s));
+    if (!Pl || nrhs < 1 || nrhs > 32) { gpx_set_error("TriSolver::mul_lower: not prepared or nrhs out of range (%d)", nrhs); return GPX_ERR_BAD_ARG; }
+    const int ng = nrhs > 16 ? 2 : 1, NC = 16 * ng;
+    const unsigned gp = (unsigned)(((npad >> 1) * NC + 255) / 256), gu = (unsigned)(((npad >> 1) * nrhs + 255) / 256);
+    hipLaunchKernelGGL(ts_pack_kernel, dim3(gp), dim3(256), 0, s, B, (long)ldb, nrhs, (long)npad, NC, W);
+    if (ng == 1)
+        hipLaunchKernelGGL((ts_rows_kernel<1, TS_LOWER>), dim3((unsigned)(npad / 16)), dim3(256), 0, s, L, (long)ld, (int)npad, (const double *)W, Y);
+    else
+        hipLaunchKernelGGL((ts_rows_kernel<2, TS_LOWER>), dim3((unsigned)(npad / 16)), dim3(256), 0, s, L, (long)ld, (int)npad, (const double *)W, Y);
+    hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)Y, (long)npad, NC, nrhs, OUT, (long)ldb);
+    GPX_HIP(hipGetLastError());
     return 0;
 }

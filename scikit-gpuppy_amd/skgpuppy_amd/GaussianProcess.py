@@ -49,6 +49,26 @@ class _DeviceModel(object):
         _gpx.check(_gpx.lib.gpx_alpha(self.handle, _gpx.ptr(out)), "gpx_alpha")
         return out
 
+    def solve(self, B, want_linv=False):
+        """K^-1 B^T for the rows of B (and L^-1 B^T): two sweeps over the factor, no K^-1."""
+        B = _gpx.f64(np.atleast_2d(B))
+        if B.shape[1] != self.n:
+            raise ValueError("right-hand sides must be rows of length %d" % self.n)
+        kb = np.empty_like(B)
+        lb = np.empty_like(B) if want_linv else None
+        _gpx.check(_gpx.lib.gpx_solve(self.handle, _gpx.ptr(B), B.shape[0], _gpx.ptr(lb) if want_linv else None, _gpx.ptr(kb)),
+                   "gpx_solve")
+        return (kb, lb) if want_linv else kb
+
+    def chol_mul(self, Z):
+        """L z for the rows of Z (a draw from N(0, K) per standard-normal row)."""
+        Z = _gpx.f64(np.atleast_2d(Z))
+        if Z.shape[1] != self.n:
+            raise ValueError("vectors must be rows of length %d" % self.n)
+        out = np.empty_like(Z)
+        _gpx.check(_gpx.lib.gpx_chol_mul(self.handle, _gpx.ptr(Z), Z.shape[0], _gpx.ptr(out)), "gpx_chol_mul")
+        return out
+
     def kinv(self):
         out = np.empty((self.n, self.n))
         _gpx.check(_gpx.lib.gpx_kinv(self.handle, _gpx.ptr(out)), "gpx_kinv")
@@ -131,11 +151,22 @@ class GaussianProcess(object):
 
     # ---- reference API -------------------------------------------------------------------------
     @staticmethod
-    def get_realisation(x, cov, theta):
-        # (GaussianProcess.py:44-57)
+    def get_realisation(x, cov, theta, size=None):
+        """(GaussianProcess.py:44-57): one draw t ~ N(0, cov_matrix(x, theta)).  The reference calls numpy's SVD-based
+        multivariate_normal on the host; here K is assembled and factored on the GPU and t = L z with z from numpy's
+        global generator (so np.random.seed governs it as in the reference -- the streams themselves differ, the
+        distribution is the same).  size=k returns k draws as rows."""
         n, d = np.shape(x)
-        K = cov.cov_matrix(x, theta)
-        return np.random.multivariate_normal(np.zeros(n), K)
+        if isinstance(cov, SPGPCovariance) or not isinstance(cov, GaussianCovariance):
+            K = cov.cov_matrix(x, theta)
+            return np.random.multivariate_normal(np.zeros(n), K, size)
+        model = _DeviceModel(_gpx.f64(x), np.zeros(n), _gpx.f64(theta))
+        try:
+            z = np.random.standard_normal((1 if size is None else int(size), n))
+            draws = model.chol_mul(z)
+        finally:
+            model.close()
+        return draws[0] if size is None else draws
 
     def __call__(self, x_star):
         return self.estimate(x_star)

@@ -47,6 +47,8 @@ SIGNATURES = {
     "gpx_spd_inverse": (_int, [_dp, _i64, _dp, ctypes.POINTER(_dbl)]),
     "gpx_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
     "gpx_alpha": (_int, [_hp, _dp]),
+    "gpx_solve": (_int, [_hp, _dp, _int, _dp, _dp]),
+    "gpx_chol_mul": (_int, [_hp, _dp, _int, _dp]),
     "gpx_kinv": (_int, [_hp, _dp]),
     "gpx_chol": (_int, [_hp, _dp]),
     "gpx_chol_rows": (_int, [_hp, _i64, _i64, _dp]),

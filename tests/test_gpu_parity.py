@@ -756,6 +756,64 @@ def test_approx_propagation_solve_path_equals_kinv_path():
     assert a0[1] == pytest.approx(float(g["approx_u0_S0"][1]), abs=1e-8 * v)
 
 
+@pytest.mark.parametrize("N,d,nrhs", [(100, 2, 1), (1024, 3, 9), (1100, 4, 17), (2500, 5, 40), (3072, 2, 16)])
+def test_solve_few_right_hand_sides_against_oracle(N, d, nrhs):
+    """gpx_solve = the fat-step triangular solver behind alpha and the post-fit propagation: one, exactly eight, nine and
+    more 128-blocks (whole and partial 1024-row steps), one and two groups of 16 right-hand sides, more than 32."""
+    import scipy.linalg
+    rng = np.random.RandomState(7 + N + nrhs)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    og = orc.OracleGP(x, t, theta)
+    B = rng.randn(nrhs, N)
+    kb, lb = gp._dev().solve(B, want_linv=True)
+    K = orc.gram(x, theta)
+    Lo = np.linalg.cholesky(K)
+    lo = scipy.linalg.solve_triangular(Lo, B.T, lower=True).T
+    np.testing.assert_allclose(lb, lo, rtol=0, atol=1e-9 * np.abs(lo).max())
+    ko = og.Kinv.dot(B.T).T
+    np.testing.assert_allclose(kb, ko, rtol=0, atol=1e-7 * np.abs(ko).max())
+    # residual of the solve itself: K (K^-1 b) = b
+    np.testing.assert_allclose(K.dot(kb.T).T, B, rtol=0, atol=1e-8 * np.abs(kb).max())
+
+
+@pytest.mark.parametrize("N,d,k", [(64, 2, 3), (1300, 3, 33)])
+def test_get_realisation_is_L_times_z(N, d, k):
+    """f4 (GaussianProcess.py:44-57): the draw is t = L z with K = cov_matrix(x, theta) assembled and factored on the GPU
+    and z from numpy's global generator -- given the same z it must equal cholesky(oracle Gram) z."""
+    rng = np.random.RandomState(3 + N)
+    x = rng.uniform(0, 10, (N, d))
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    Lo = np.linalg.cholesky(orc.gram(x, theta))
+    np.random.seed(1234)
+    draws = sk.GaussianProcess.get_realisation(x, sk.GaussianCovariance(), theta, size=k)
+    np.random.seed(1234)
+    z = np.random.standard_normal((k, N))
+    assert draws.shape == (k, N)
+    np.testing.assert_allclose(draws, z.dot(Lo.T), rtol=0, atol=1e-10 * np.abs(draws).max())
+    np.random.seed(99)
+    one = sk.GaussianProcess.get_realisation(x, sk.GaussianCovariance(), theta)     # the reference's signature
+    np.random.seed(99)
+    np.testing.assert_allclose(one, Lo.dot(np.random.standard_normal(N)), rtol=0, atol=1e-10 * np.abs(one).max())
+
+
+def test_get_realisation_distribution():
+    """Sample covariance of 4000 draws at N = 64 against K (the only parity the reference's SVD-based sampler allows:
+    its random stream cannot be reproduced).  Entry-wise standard error of a sample covariance is
+    sqrt((K_ii K_jj + K_ij^2) / n) <= 2.01 sqrt(2 / 4000) = 0.045; 5 sigma."""
+    rng = np.random.RandomState(11)
+    x = rng.uniform(0, 10, (64, 2))
+    theta = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
+    K = orc.gram(x, theta)
+    np.random.seed(2024)
+    T = sk.GaussianProcess.get_realisation(x, sk.GaussianCovariance(), theta, size=4000)
+    assert abs(T.mean(0)).max() < 5 * np.sqrt(2.01 / 4000)
+    S = T.T.dot(T) / 4000
+    assert abs(S - K).max() < 5 * 2.01 * np.sqrt(2.0 / 4000)
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 384, 48), (384, 1408, 64), (2048, 3072, 32)])
 def test_gemm_nt_trapezoid(M, N, K):
     """lower_only with N > M: the first N - M columns are full, the remaining square is lower-triangular by 128-tiles
