@@ -539,15 +539,19 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
     if (m == 0) return 0;
     hipStream_t s = h->stream;
     const int d = h->d;
-    int64_t cap = ((int64_t)8 << 30) / (h->npad * (int64_t)sizeof(double));
+    int64_t cap = ((int64_t)8 << 30) / (h->npad * (int64_t)sizeof(double));   // rows per 8 GB buffer (two of them: Z and Zs)
     cap = std::max<int64_t>(TILE, cap / TILE * TILE);
     cap = std::min<int64_t>(cap, 32768);
     const int64_t chunk = std::min<int64_t>(round_up(m, TILE), cap);
     GPX_TRY(ensure_Z(h, chunk));
-    double *xq = nullptr, *xqw = nullptr, *mv = nullptr;
-    GPX_TRY(dalloc(&xq, chunk * d));
+    // the triangular solve runs out of place against the inverted diagonal squares (tsolve.hip): second slab-major buffer
+    double *xq = nullptr, *xqw = nullptr, *mv = nullptr, *Zs = nullptr;
+    GPX_TRY(dalloc(&Zs, chunk * h->npad));
     int rc = 0;
-    if ((rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) { dfree(xq); if (xqw) dfree(xqw); return rc; }
+    if ((rc = dalloc(&xq, chunk * d)) || (rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) {
+        dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw);
+        return rc;
+    }
     for (int64_t m0 = 0; m0 < m && rc == 0; m0 += chunk) {
         const int64_t mc = std::min<int64_t>(chunk, m - m0), mp = round_up(mc, TILE);
         hipError_t e = hipMemcpyAsync(xq, xs + m0 * d, sizeof(double) * mc * d, hipMemcpyDefault, s);
@@ -556,15 +560,16 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
         // kv = cross-covariance (no vt), zero padded: rows >= mc and columns >= n are 0
         if ((rc = launch_gram(xqw, mc, h->xs_w, h->n, d, h->v, 0.0, 0, 1, h->Z, h->npad, mp, h->npad, s, &h->prof))) break;
         // Z <- kv L^-T  : row m of Z is (L^-1 kv_m)^T
-        if ((rc = trsm_right_lt(h->Z, h->npad, mp, h->L, h->npad, h->Dinv, 0, h->nblk, s, &h->prof))) break;
+        if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof))) break;
         // var = v + vt - |z|^2 ; mean = z . y   (k includes vt: GaussianProcess.py:75,78)
-        if ((rc = launch_predict_reduce(h->Z, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof))) break;
+        if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof))) break;
         e = hipMemcpyAsync(mean_out + m0, mv, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipMemcpyAsync(var_out + m0, mv + chunk, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) { gpx_set_error("predict copy-out failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
     }
     (void)hipStreamSynchronize(s);
+    dfree(Zs);
     dfree(xq);
     dfree(xqw);
     dfree(mv);

@@ -54,9 +54,11 @@ __device__ __forceinline__ double bperm_f64(double v, int byte_index)
     return __hiloint2double(hi, lo);
 }
 
-// X: packed lower blocks A -> L -> inverse (in place); Xd: inv(L_bb), b = 0..7; Gs: inv(L_d)^T of the current panel
+// X: packed lower blocks A -> L -> inverse (in place); Gs: inv(L_d)^T of the current panel.  The inverses of the eight
+// diagonal 16-blocks wait in their final place in `dinv` (global) until the factor has left the LDS: the leaf's footprint
+// stays at 80 KB, which fits next to one bulk GEMM workgroup (64 KB) on a CU with room to spare.
 __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
-                                               double *X, double *Xd, double *Gs, int *bad_sp)
+                                               double *X, double *Gs, int *bad_sp)
 {
 #define bad_s (*bad_sp)
     const int t = threadIdx.x;
@@ -133,7 +135,7 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
                 Db[fr * 17 + c] = (c <= fr) ? e[m] : 0.0;
                 const double gv = (c >= fr) ? g[m] : 0.0;                        // inv(L_d)^T[fr][c] = inv(L_d)[c][fr]
                 Gs[fr * 17 + c] = gv;
-                Xd[jb * XB + c * 17 + fr] = gv;
+                dinv[(16 * jb + c) * TILE + 16 * jb + fr] = gv;
             }
             if (bad && lane == 0 && bad_s == 0) bad_s = bad;
         }
@@ -207,7 +209,7 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
     __syncthreads();
     for (int e = t; e < 8 * 256; e += 256) {
         const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        X[xblk(b, b) + r * 17 + c] = Xd[b * XB + r * 17 + c];
+        X[xblk(b, b) + r * 17 + c] = dinv[(16 * b + r) * TILE + 16 * b + c];
     }
     __syncthreads();
 
@@ -300,11 +302,10 @@ __global__ __launch_bounds__(256) void potrf_trtri128_mfma_kernel(double *A, lon
                                                                  int col_offset)
 {
     __shared__ __attribute__((aligned(16))) double X[36 * XB];
-    __shared__ __attribute__((aligned(16))) double Xd[8 * XB];
     __shared__ __attribute__((aligned(16))) double Gs[XB];
     __shared__ int bad_s;
     __builtin_amdgcn_s_setprio(3);
-    leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Xd, Gs, &bad_s);
+    leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Gs, &bad_s);
 }
 
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,

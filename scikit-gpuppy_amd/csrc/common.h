@@ -124,7 +124,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
 int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
-                   hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0);
+                   hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0, int tri = 0);
 // batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
 // tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
 enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3 };
@@ -142,6 +142,11 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);
+// out of place, in steps of whole diagonal squares (1024 columns) against their inverses: Zs[:, p0..p1) <- Z[:, p0..p1) L^-T
+// (Z is consumed; p0, p1 in units of squares).  The solver must be prepared for the same factor.
+struct TriSolver;
+int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, const TriSolver *ts, int64_t p0, int64_t p1,
+                          hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);

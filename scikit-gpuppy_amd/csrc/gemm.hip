@@ -26,17 +26,12 @@ __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
 // (4,4) -> 128x128, the bulk kernel; (2,2) -> 64x64 and (2,4)/(1,4) -> 64x128 / 32x128 for the short, skinny
 // products on the factorisation's critical path, where a 128-tile grid would leave most of the 256 CUs idle
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
-template <int WM, int WN, bool LOWER>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
-                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
-                                                            GemmBatch ba, GemmBatch bb, GemmBatch bc)
+//
+// gemm_tile: one block tile (by, bx) of C over the contraction range [kstart, kend).  smem: two stages, 1024-aligned.
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_tile(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int bx, int by,
+                                          long kstart, int kend, double alpha, double beta, double *smem)
 {
-    if (ba.nq) {   // batched launch: problem blockIdx.z = (p, q), operands at base + p * sp + q * sq
-        const int z = blockIdx.z, p = z / ba.nq, q = z - p * ba.nq;
-        A += p * ba.sp + q * ba.sq;
-        B += p * bb.sp + q * bb.sq;
-        C += p * bc.sp + q * bc.sq;
-    }
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
     // ONE LDS array: per stage an A image [BTM][16] and a B image [BTN][16] of doubles (128-byte rows, no padding),
@@ -45,64 +40,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     // the SOURCE address and again on the fragment reads: the 32 lanes of a ds_read_b64 half then hit 32
     // distinct 8-byte slots of the 256-byte bank row.
     constexpr int STAGE = (BTM + BTN) * 16;
-    constexpr int NBUF = 2;
-    __shared__ __attribute__((aligned(1024))) double smem[NBUF * STAGE];
-
-    int bx, by;   // bx: column tile, by: row tile
-    {
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int nwg = gx * gy;
-        const int orig = blockIdx.y * gx + blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-        // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
-        const int lid = ktrim ? orig : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);   // bijective for any nwg
-        if (LOWER) {
-            // 1-D grid over the needed tiles only.  Row by holds the tiles bx <= by + tri_off: tri_off = 0 is the lower
-            // triangle of a square C; tri_off > 0 a trapezoid whose first tri_off tile columns are full.  The tiles are
-            // walked in groups of GL = 8 tile rows, column-major inside a group (then the group's small triangle), so the 64
-            // tiles resident on an XCD at any time form an 8 x 8 block of C that shares 8 A and 8 B row panels through that
-            // XCD's L2 (a plain row-major walk of the triangle streams 64 different B panels per XCD: 7x the algorithmic
-            // HBM traffic measured).  Group g (full) holds 8 (tri_off + 8 g) + 36 tiles; S(g) = g (8 tri_off + 32 g + 4).
-            constexpr int GL = 8;
-            const int nt = tri_rows;                       // tile rows of the launch
-            const double b2 = 8.0 * (double)tri_off + 4.0;
-            int g = (int)((sqrt(b2 * b2 + 128.0 * (double)lid) - b2) * (1.0 / 64.0));
-            while (g > 0 && g * (8 * tri_off + 32 * g + 4) > lid) --g;
-            while ((g + 1) * (8 * tri_off + 32 * (g + 1) + 4) <= lid && (g + 1) * GL < nt) ++g;
-            const int rem = lid - g * (8 * tri_off + 32 * g + 4);
-            const int first = g * GL;
-            const int rows = (nt - first) < GL ? (nt - first) : GL;
-            const int rect = rows * (tri_off + first);     // tiles left of the group's diagonal block
-            if (rem < rect) {
-                bx = rem / rows;
-                by = first + rem - bx * rows;
-            } else {
-                const int r2 = rem - rect;                 // row-major walk of the rows x rows lower triangle
-                int j = (int)((sqrt(8.0 * (double)r2 + 1.0) - 1.0) * 0.5);
-                while (j * (j + 1) / 2 > r2) --j;
-                while ((j + 1) * (j + 2) / 2 <= r2) ++j;
-                by = first + j;
-                bx = tri_off + first + (r2 - j * (j + 1) / 2);
-            }
-        } else {
-            // XCD-aware order: contiguous chunk of the logical tile order per XCD, walked in groups of GM row tiles
-            constexpr int GM = 8;
-            const int per_group = GM * gx;
-            const int g = lid / per_group, rem = lid - g * per_group;
-            const int first = g * GM;
-            const int rows = (gy - first) < GM ? (gy - first) : GM;
-            by = first + rem % rows;
-            bx = rem / rows;
-        }
-    }
-
-    if (ba.nq) {
-        // batched launches with a triangular operand: tile lengths depend on by (or bx), and the dispatcher hands tile
-        // (by, bx) of every problem to the same CU / XCD -- rotate the tile coordinates with the problem index so that
-        // every CU sees the whole mix of lengths
-        by = (by + (int)blockIdx.z) % (int)gridDim.y;
-        bx = (bx + (int)blockIdx.z) % (int)gridDim.x;
-    }
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     const int wr = wave >> 1, wc = wave & 1;
@@ -113,22 +50,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     // scalar unit) + (32-bit per-lane byte offset inside the tile: a VGPR that never changes) -- no vector arithmetic
     // per stage (fp64 MFMAs do not co-issue with other VALU work: SQ_VALU_MFMA_COEXEC_CYCLES = 0).
     const int drow = lane >> 3;
-    // ktrim (lower-only launches): both operands are UPPER triangular in their own index space (operand[i][k] = 0 for
-    // k < i), so tile (by, bx <= by) contracts over k >= by * BTM only -- K^-1 = L^-T L^-1 as one launch
-    // Rectangular launches: A alone is upper triangular with its diagonal shifted by ktrim - 1 columns to the left of its
-    // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
-    // k = max(0, by * BTM - (ktrim - 1)).
-    long kstart = 0;
-    int kend = K;
-    if (ktrim) {
-        kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
-        if (kstart < 0) kstart = 0;
-        if (kstart > K) kstart = K;
-    }
-    // batched launches (square problems, M = N = K): one triangular operand, GemmBatch::tri of the A descriptor
-    if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
-    else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
-    else if (ba.tri == GEMM_TRI_B_LOWER) kend = min(K, (bx + 1) * BTN);            // B[j][k] = 0 for k > j
     const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda + kstart);
     const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb + kstart);
     unsigned aoff[(BTM / 8 + 3) / 4], boff[(BTN / 8 + 3) / 4];
@@ -267,11 +188,114 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 }
 
 
+
+// lid -> (by, bx) of a lower-only launch.  1-D grid over the needed tiles only.  Row by holds the tiles bx <= by + tri_off:
+// tri_off = 0 is the lower triangle of a square C; tri_off > 0 a trapezoid whose first tri_off tile columns are full.
+// The tiles are walked in groups of GL = 8 tile rows, column-major inside a group (then the group's small triangle), so
+// the 64 tiles resident on an XCD at any time form an 8 x 8 block of C that shares 8 A and 8 B row panels through that
+// XCD's L2 (a plain row-major walk of the triangle streams 64 different B panels per XCD: 7x the algorithmic HBM
+// traffic measured).  Group g (full) holds 8 (tri_off + 8 g) + 36 tiles; S(g) = g (8 tri_off + 32 g + 4).
+__device__ __forceinline__ void lower_tile(int lid, int tri_off, int nt, int &by, int &bx)
+{
+    constexpr int GL = 8;
+    const double b2 = 8.0 * (double)tri_off + 4.0;
+    int g = (int)((sqrt(b2 * b2 + 128.0 * (double)lid) - b2) * (1.0 / 64.0));
+    while (g > 0 && g * (8 * tri_off + 32 * g + 4) > lid) --g;
+    while ((g + 1) * (8 * tri_off + 32 * (g + 1) + 4) <= lid && (g + 1) * GL < nt) ++g;
+    const int rem = lid - g * (8 * tri_off + 32 * g + 4);
+    const int first = g * GL;
+    const int rows = (nt - first) < GL ? (nt - first) : GL;
+    const int rect = rows * (tri_off + first);     // tiles left of the group's diagonal block
+    if (rem < rect) {
+        bx = rem / rows;
+        by = first + rem - bx * rows;
+    } else {
+        const int r2 = rem - rect;                 // row-major walk of the rows x rows lower triangle
+        int j = (int)((sqrt(8.0 * (double)r2 + 1.0) - 1.0) * 0.5);
+        while (j * (j + 1) / 2 > r2) --j;
+        while ((j + 1) * (j + 2) / 2 <= r2) ++j;
+        by = first + j;
+        bx = tri_off + first + (r2 - j * (j + 1) / 2);
+    }
+}
+
+// XCD-aware order of a launch of nwg workgroups: the hardware deals workgroups round-robin over the 8 XCDs; workgroup
+// orig on XCD (orig & 7) takes the (orig >> 3)-th tile of that XCD's contiguous chunk of the logical order (bijective for any nwg)
+__device__ __forceinline__ int xcd_chunk_start(int nwg, int xcd)
+{
+    const int q = nwg >> 3, r = nwg & 7;
+    return xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+}
+
+template <int WM, int WN, bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
+                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
+                                                            GemmBatch ba, GemmBatch bb, GemmBatch bc)
+{
+    constexpr int BTM = 32 * WM, BTN = 32 * WN;
+    __shared__ __attribute__((aligned(1024))) double smem[2 * (BTM + BTN) * 16];
+    if (ba.nq) {   // batched launch: problem blockIdx.z = (p, q), operands at base + p * sp + q * sq
+        const int z = blockIdx.z, p = z / ba.nq, q = z - p * ba.nq;
+        A += p * ba.sp + q * ba.sq;
+        B += p * bb.sp + q * bb.sq;
+        C += p * bc.sp + q * bc.sq;
+    }
+    int bx, by;   // bx: column tile, by: row tile
+    {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy;
+        const int orig = blockIdx.y * gx + blockIdx.x;
+        // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
+        const int lid = ktrim ? orig : xcd_chunk_start(nwg, orig & 7) + (orig >> 3);
+        if (LOWER) lower_tile(lid, tri_off, tri_rows, by, bx);
+        else if (!ba.nq && ba.tri == GEMM_TRI_B_LOWER) {
+            // column tile bx contracts over (bx + 1) * BTN only: longest tiles first, in dispatch order, so that the short
+            // ones fill the tail of the launch
+            bx = gx - 1 - orig / gy;
+            by = orig - (gx - 1 - bx) * gy;
+        } else {
+            // walked in groups of GM row tiles
+            constexpr int GM = 8;
+            const int per_group = GM * gx;
+            const int g = lid / per_group, rem = lid - g * per_group;
+            const int first = g * GM;
+            const int rows = (gy - first) < GM ? (gy - first) : GM;
+            by = first + rem % rows;
+            bx = rem / rows;
+        }
+    }
+    if (ba.nq) {
+        // batched launches with a triangular operand: tile lengths depend on by (or bx), and the dispatcher hands tile
+        // (by, bx) of every problem to the same CU / XCD -- rotate the tile coordinates with the problem index so that
+        // every CU sees the whole mix of lengths
+        by = (by + (int)blockIdx.z) % (int)gridDim.y;
+        bx = (bx + (int)blockIdx.z) % (int)gridDim.x;
+    }
+    // ktrim (lower-only launches): both operands are UPPER triangular in their own index space (operand[i][k] = 0 for
+    // k < i), so tile (by, bx <= by) contracts over k >= by * BTM only -- K^-1 = L^-T L^-1 as one launch
+    // Rectangular launches: A alone is upper triangular with its diagonal shifted by ktrim - 1 columns to the left of its
+    // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
+    // k = max(0, by * BTM - (ktrim - 1)).
+    long kstart = 0;
+    int kend = K;
+    if (ktrim) {
+        kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
+        if (kstart < 0) kstart = 0;
+        if (kstart > K) kstart = K;
+    }
+    // batched launches (square problems, M = N = K): one triangular operand, GemmBatch::tri of the A descriptor
+    if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
+    else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
+    else if (ba.tri == GEMM_TRI_B_LOWER) kend = min(K, (bx + 1) * BTN);            // B[j][k] = 0 for k > j
+    gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
+}
+
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
 constexpr double SMALL_GRID_TILES = 192.0;
 
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
-                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles, int ktrim)
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles, int ktrim,
+                   int tri)
 {
     if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
@@ -292,6 +316,10 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: ktrim on a lower-only launch needs a square C with K == M");
         return GPX_ERR_BAD_ARG;
     }
+    if (tri && (lower_only || ktrim || (tri == GEMM_TRI_B_LOWER ? K != N : K != M))) {
+        gpx_set_error("launch_gemm_nt: a triangular operand needs a plain launch with K equal to that operand's other dimension");
+        return GPX_ERR_BAD_ARG;
+    }
     if (ktrim && !lower_only && (ktrim - 1) % GEMM_BK) {
         gpx_set_error("launch_gemm_nt: ktrim shift must be a multiple of %d", GEMM_BK);
         return GPX_ERR_BAD_ARG;
@@ -299,25 +327,27 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     const int64_t trap = lower_only ? N - M : 0;   // full columns left of the triangle
     const double tiles = lower_only ? 0.5 * (double)(M / TILE) * (double)(M / TILE + 1) + (double)(trap / TILE) * (double)(M / TILE)
                                     : (double)(M / TILE) * (double)(N / TILE);
-    // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2
-    ProfScope ps(prof, s, tiles >= SMALL_GRID_TILES ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K,
+    // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2.
+    // Work = the flops issued: a triangular operand halves the contraction (sum over tile rows / columns of their length).
+    const double kfrac = tri ? 0.5 * (1.0 + (double)TILE / (double)K) : 1.0;
+    ProfScope ps(prof, s, tiles >= SMALL_GRID_TILES ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K * kfrac,
                  tiles >= SMALL_GRID_TILES ? 1 : 2);
     const bool in_place = (C == A || C == B);   // in-place TRSM leaves: exactly one column tile per row block
     if (in_place && N != TILE) {
         gpx_set_error("launch_gemm_nt: in-place product needs N == %d", TILE);
         return GPX_ERR_BAD_ARG;
     }
-    const GemmBatch nb_ = {0, 0, 0, 0};
+    const GemmBatch nb_ = {0, 0, 0, 0}, na_ = {0, 0, 0, tri};   // tri: one triangular operand (GEMM_TRI_*), square K == N or K == M
 #define GPX_LAUNCH(WM_, WN_)                                                                                          \
     do {                                                                                                              \
         dim3 grid((unsigned)(N / (32 * WN_)), (unsigned)(M / (32 * WM_)));                                            \
         const unsigned nt_ = (unsigned)(M / (32 * WM_)), off_ = (unsigned)(trap / (32 * WN_));                        \
         if (lower_only)                                                                                               \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, true>), dim3(nt_ * (nt_ + 1) / 2 + off_ * nt_), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, (int)off_, ktrim, (int)nt_, nb_, nb_, nb_);                   \
+                               (long)ldc, (int)K, alpha, beta, (int)off_, ktrim, (int)nt_, na_, nb_, nb_);                   \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
-                               (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, nb_, nb_, nb_);                                  \
+                               (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, na_, nb_, nb_);                                  \
     } while (0)
     if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles

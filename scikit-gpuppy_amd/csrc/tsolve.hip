@@ -353,3 +353,30 @@ int TriSolver::mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hi
     GPX_HIP(hipGetLastError());
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Many right-hand sides (estimate_many's  kv L^-T, skgpuppy/GaussianProcess.py:77-78): the recursive TRSM with whole
+// diagonal squares as leaves.  A leaf is ONE product with the square's inverse, Zs_p = Z_p inv(L_pp)^T (128 x 128-tile
+// GEMM with K = 1024 that skips the zero triangle of the inverse), instead of the 8 leaf products and 7 short-K updates
+// (K = 128 .. 512, launch- and fill-bound at 44 TFLOP/s) it replaces.  Out of place -- a row block's column tiles read
+// the whole 1024-column slab -- so solved slabs live in Zs and the updates read them from there.
+// ------------------------------------------------------------------------------------------------------------------
+int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, const TriSolver *ts, int64_t p0, int64_t p1, hipStream_t s,
+                          Profiler *prof)
+{
+    const int64_t np = p1 - p0;
+    if (np <= 0 || rows <= 0) return 0;
+    if (!ts || !ts->Pl) { gpx_set_error("trsm_right_lt_squares: solver not prepared"); return GPX_ERR_STATE; }
+    if (np == 1) {
+        const int64_t k0 = p0 * PB, K = std::min<int64_t>(PB, ts->npad - k0);
+        return launch_gemm_nt(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, K, 1.0, 0.0, 0, s, prof, 0, 0, GEMM_TRI_B_LOWER);
+    }
+    int64_t h = 1;
+    while (h * 2 < np) h *= 2;
+    const int64_t pm = p0 + h;
+    GPX_TRY(trsm_right_lt_squares(Z, Zs, ldz, rows, ts, p0, pm, s, prof));
+    // Z[:, pm..p1) -= Zs[:, p0..pm) L[pm..p1, p0..pm)^T
+    const int64_t c0 = p0 * PB, cm = pm * PB, c1 = std::min<int64_t>(p1 * PB, ts->npad);
+    GPX_TRY(launch_gemm_nt(Zs + c0, ldz, ts->L + cm * ts->ld + c0, ts->ld, Z + cm, ldz, rows, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
+    return trsm_right_lt_squares(Z, Zs, ldz, rows, ts, pm, p1, s, prof);
+}
