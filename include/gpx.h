@@ -108,6 +108,13 @@ int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, double *H);
 int gpx_propagate_approx(gpx_handle *h, const double *u, const double *Sigma,
                          double *mean, double *var, double *sigma2, double *rest);
 
+/* Row-sharded form for the multi-GPU host (last row): the 4 + 2 d sums behind gpx_propagate_approx restricted to
+ * rows [row0, row1) of K^-1 (row0 a multiple of GPX_TILE, row1 a multiple of GPX_TILE or n).  partial_out [4 + 2 d]:
+ * beta.C, beta.tr, C.KinvC, KinvC.tr, then per k: J_k.KinvJ_k, beta.J_k.  The ranks add their partials (ONE all-reduce of
+ * 4 + 2 d doubles) and finish on the host: skgpuppy_amd.distributed.combine_approx_partials. */
+int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1,
+                              double *partial_out);
+
 /* ---- a13: UncertaintyPropagationApprox._get_variance_dv_h for every h in [0,d)
  * (skgpuppy/UncertaintyPropagation.py:564-630, UncertaintyPropagation2.pyx:340-380) ---- */
 int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out /* [d] */);
@@ -184,8 +191,9 @@ int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, 
 int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset, void *stream);
 
 /* factor block columns [B0,B1) (units of GPX_TILE) of the row-major matrix L (ld, nblk block rows), all updates
- * from columns < B0 already applied: diagonal square 128 columns at a time + one recursive TRSM for the rows
- * below.  This is the per-panel step the multi-GPU host (skgpuppy_amd/distributed.py) runs on the panel owner. */
+ * from columns < B0 already applied: the diagonal square 128 columns at a time on `stream`, the rows below it solved
+ * column by column on an internal side stream alongside that chain (forked from and joined back into `stream`).  This is
+ * the per-panel step the multi-GPU host (skgpuppy_amd/distributed.py) runs on the panel owner. */
 int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *dinv, double *diag,
                        int *info_dev, void *stream);
 /* build a handle around an EXISTING factor in HBM (L [npad,npad] with ld == npad, dinv [npad/128,128,128],

@@ -18,7 +18,7 @@
 int launch_nll_grad(const double *Kinv, int64_t ld, int64_t n, int64_t npad, int d, const double *alpha, const double *xw,
                     double v, double *partial, double *out_dev, int *dmax_used, hipStream_t s, Profiler *prof);
 int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const double *V, double *KV, hipStream_t s,
-                     Profiler *prof);
+                     Profiler *prof, int64_t nrows = 0);
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
 int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
                      const double *bT, const double *e, const double *F, double *partial, double *out_dev, hipStream_t s,
@@ -355,7 +355,7 @@ extern "C" int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B
         gpx_set_error("gpx_dev_chol_panel: bad arguments");
         return GPX_ERR_BAD_ARG;
     }
-    return chol_panel_factor(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr);
+    return chol_panel_factor_piped(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr);
 }
 
 // ---- fit ---------------------------------------------------------------------------------------
@@ -834,6 +834,57 @@ extern "C" int gpx_propagate_approx(gpx_handle *h, const double *u, const double
     if (sigma2) *sigma2 = s2;
     if (rest) *rest = var2 + var3;
     if (var) *var = s2 + var2 + var3;
+    return 0;
+}
+
+// Row-sharded form of the Approx propagation (last row): the 4 + 2 d sums of gpx_propagate_approx restricted to
+// the rows [row0, row1) of K^-1 -- (K^-1 v)_i needs row i of K^-1 only, and every quadratic form is a sum over i.  The
+// caller adds the partials of all row panels (one all-reduce of 4 + 2 d doubles across the ranks) and finishes with
+// skgpuppy_amd.distributed.combine_approx_partials.  partial_out: 0 beta.C  1 beta.tr  2 C.KinvC  3 KinvC.tr, then per k:
+// J_k.KinvJ_k, beta.J_k.  row0 must be a multiple of 128; row1 a multiple of 128 or n.
+extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1,
+                                         double *partial_out)
+{
+    CHECK_H(h);
+    if (!u || !Sigma || !partial_out || row0 < 0 || row1 < row0 || row1 > h->n || (row0 % TILE && row0 != h->n) || (row1 % TILE && row1 != h->n)) {
+        gpx_set_error("gpx_propagate_approx_rows: bad arguments (rows [%ld, %ld) of %ld)", (long)row0, (long)row1, (long)h->n);
+        return GPX_ERR_BAD_ARG;
+    }
+    const int d = h->d;
+    const int64_t np = h->npad;
+    hipStream_t s = h->stream;
+    GPX_TRY(ensure_kinv(h));
+    GPX_TRY(ensure_prop_buffers(h));
+    h->have_u = false;   // KV is about to hold a row panel only
+    double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
+    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpyAsync(udev_ptr(h), uh, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipMemcpyAsync(sigma_ptr(h), Sh, sizeof(double) * d * d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipStreamSynchronize(s));   // stack buffers
+    GPX_TRY(launch_approx_build(h->x, h->n, np, d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
+    double *tr = aux_ptr(h);
+    GPX_TRY(launch_trace(h->x, h->n, np, d, udev_ptr(h), h->wdev, sigma_ptr(h), cplain_ptr(h), tr, s));
+    const int64_t r1p = round_up(row1, TILE), len = row1 > row0 ? r1p - row0 : 0;   // rows past n are padding: V and tr are zero there
+    const int npair = 4 + 2 * d;
+    if (len > 0) {
+        GPX_TRY(launch_kinv_pass(h->Kinv + row0 * np, np, np, d + 1, h->V, h->KV + row0, s, &h->prof, len));
+        std::vector<std::pair<const double *, const double *>> pr;
+        const double *C = h->V + row0, *KC = h->KV + row0, *al = h->alpha + row0, *trr = tr + row0;
+        pr.push_back({al, C});
+        pr.push_back({al, trr});
+        pr.push_back({C, KC});
+        pr.push_back({KC, trr});
+        for (int k = 0; k < d; ++k) {
+            pr.push_back({h->V + (int64_t)(k + 1) * np + row0, h->KV + (int64_t)(k + 1) * np + row0});
+            pr.push_back({al, h->V + (int64_t)(k + 1) * np + row0});
+        }
+        GPX_TRY(launch_dot_pairs(pr, len, out_ptr(h), s));
+    } else GPX_HIP(hipMemsetAsync(out_ptr(h), 0, sizeof(double) * npair, s));
+    double o[4 + 2 * GPX_MAX_D];
+    GPX_HIP(hipMemcpyAsync(o, out_ptr(h), sizeof(double) * npair, hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipStreamSynchronize(s));
+    GPX_HIP(hipMemcpy(partial_out, o, sizeof(double) * npair, hipMemcpyDefault));
     return 0;
 }
 

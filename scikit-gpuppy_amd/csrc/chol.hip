@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
@@ -477,6 +478,54 @@ int chol_panel_factor(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64
     if (nblk_all > B1)
         GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk_all - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
     return 0;
+}
+
+static void retire_events(const std::vector<hipEvent_t> &fresh)
+{
+    static std::mutex mu;
+    static std::vector<hipEvent_t> pending;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t keep = 0;
+    for (size_t i = 0; i < pending.size(); ++i) {
+        if (hipEventQuery(pending[i]) == hipSuccess) (void)hipEventDestroy(pending[i]);
+        else pending[keep++] = pending[i];
+    }
+    pending.resize(keep);
+    pending.insert(pending.end(), fresh.begin(), fresh.end());
+}
+
+// The same with the rows below the square solved column by column on a side stream alongside the chain (TopPipe, as in
+// chol_factor): the multi-GPU host's panel owner runs this.  Fork / join inside: on return everything is ordered behind `s`.
+int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
+                            int *info_dev, hipStream_t s, Profiler *prof)
+{
+    if (nblk_all <= B1) return chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof);
+    hipStream_t st = stream_acquire(1);
+    if (!st) return chol_panel_factor(L, ld, nblk_all, B0, B1, Dinv, diagL, info_dev, s, prof);
+    std::vector<hipEvent_t> events;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto run = [&]() -> int {
+        GPX_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        GPX_HIP(hipEventRecord(e0, s));
+        GPX_HIP(hipStreamWaitEvent(st, e0, 0));
+        TopPipe top;
+        top.stream = st; top.r0 = B1; top.r1 = nblk_all; top.events = &events;
+        GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof, &top));
+        GPX_HIP(hipEventRecord(e1, st));
+        GPX_HIP(hipStreamWaitEvent(s, e1, 0));
+        return 0;
+    };
+    const int rc = run();
+    // No host synchronisation here: the caller goes on queueing its trailing updates while the panel is being factored.
+    // The events are still referenced by queued waits, so they retire through a list that later calls sweep once
+    // hipEventQuery says the GPU has passed them; the side stream goes back to the cache (whoever takes it next queues
+    // behind the work it still holds).
+    if (e0) events.push_back(e0);
+    if (e1) events.push_back(e1);
+    retire_events(events);
+    stream_release(st, 1);
+    return rc;
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,

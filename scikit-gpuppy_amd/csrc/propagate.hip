@@ -151,18 +151,20 @@ __global__ __launch_bounds__(256) void kinv_pass_kernel(const double *__restrict
     }
 }
 
+// nrows (> 0): only the first nrows rows of the Kinv pointer passed (a row panel; KV offset accordingly by the caller)
 int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const double *V, double *KV, hipStream_t s,
-                     Profiler *prof)
+                     Profiler *prof, int64_t nrows)
 {
-    ProfScope ps(prof, s, GPX_K_QUAD, 8.0 * (double)npad * (double)npad);
+    const int64_t nr = nrows > 0 ? nrows : npad;   // a multiple of 8
+    ProfScope ps(prof, s, GPX_K_QUAD, 8.0 * (double)nr * (double)npad);
     if (nc <= 9)
-        hipLaunchKernelGGL((kinv_pass_kernel<9, 8>), dim3((unsigned)(npad / 8)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+        hipLaunchKernelGGL((kinv_pass_kernel<9, 8>), dim3((unsigned)(nr / 8)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
     else if (nc <= 17)
-        hipLaunchKernelGGL((kinv_pass_kernel<17, 4>), dim3((unsigned)(npad / 4)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+        hipLaunchKernelGGL((kinv_pass_kernel<17, 4>), dim3((unsigned)(nr / 4)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
     else if (nc <= 33)
-        hipLaunchKernelGGL((kinv_pass_kernel<33, 2>), dim3((unsigned)(npad / 2)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+        hipLaunchKernelGGL((kinv_pass_kernel<33, 2>), dim3((unsigned)(nr / 2)), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
     else
-        hipLaunchKernelGGL((kinv_pass_kernel<65, 1>), dim3((unsigned)npad), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
+        hipLaunchKernelGGL((kinv_pass_kernel<65, 1>), dim3((unsigned)nr), dim3(256), 0, s, Kinv, (long)ld, (long)npad, nc, V, KV);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -6,14 +6,19 @@ right-looking Cholesky (csrc/chol.hip):
 
   * the N x N matrix is cut into outer panels of PANEL_BLOCKS x 128 columns; rank r owns panels p = r (mod R);
   * K-build: every rank assembles only the Gram columns of its own panels (no communication);
-  * factorisation, per panel p: the owner factors it (gpx_dev_chol_panel: diagonal chain + one recursive TRSM),
-    the panel (rows below its diagonal, 1024 wide) + its inverted diagonal blocks are BROADCAST (the path's one
-    real exchange step), every rank applies the rank-1024 update to the panels it owns.  Look-ahead: the owner of
-    panel p+1 updates and factors it first and its broadcast is posted asynchronously, so the transfer overlaps
-    with the remaining updates of step p;
-  * every rank unpacks each received panel into its own copy of L, so after the last step all ranks hold the
-    complete factor (34 GB at N = 65536: fits one 288 GB MI355X) and `estimate_many` shards the QUERIES with no
-    further communication; alpha is solved redundantly per rank (4 N^2 bytes of HBM traffic, no exchange).
+  * factorisation, per panel p: the owner factors it on a high-priority side stream (gpx_dev_chol_panel: diagonal chain
+    with the rows below solved column by column alongside), the panel (rows from its diagonal down, 1024 wide) with its
+    inverted diagonal blocks and diagonal is BROADCAST as ONE contiguous message (the path's one real exchange step;
+    large messages go as scatter + all-gather, which keeps all seven xGMI links of the source busy instead of one
+    ring), every rank applies the rank-1024 update to the panels it owns, reading the panel straight from the receive
+    buffer.  Look-ahead: the owner of panel p+1 updates and factors it first, on the side stream, and its broadcast is
+    posted from there, so factorisation and transfer overlap with the remaining updates of step p on the main stream;
+  * two pre-allocated staging buffers per rank (panels p and p+1); received panels are copied into the rank's own L
+    off the critical path, so after the last step all ranks hold the complete factor (34 GB at N = 65536: fits one
+    288 GB MI355X) and `estimate_many` shards the QUERIES with no further communication; alpha is solved
+    redundantly per rank (two HBM-bound sweeps, no exchange);
+  * a non-positive pivot is agreed on by all ranks (all-reduce MAX of the info word) and answered collectively with the
+    reference's retry on K + 1e-5 I (skgpuppy/Covariance.py:180-185), exactly like the single-GPU gpx_fit.
 
 The schedule (`panel_cholesky`) is written against a small `ops` interface so that it runs unchanged on CPU
 tensors with the gloo backend (tests/test_distributed_gloo.py supplies a torch-CPU `ops`); `GpxOps` is the
@@ -29,6 +34,7 @@ import numpy as np
 
 TILE = 128
 PANEL_BLOCKS = 8     # outer panel = 8 x 128 = 1024 columns (same as csrc/chol.hip CHOL_NBP)
+JITTER = 1e-5        # skgpuppy/Covariance.py:182
 
 
 class PanelLayout(object):
@@ -52,66 +58,113 @@ class PanelLayout(object):
     def owned(self, rank):
         return [p for p in range(self.npanels) if self.owner(p) == rank]
 
+    def message_elems(self, p):
+        """doubles in the broadcast message of panel p: rows from the diagonal down x width | inverted diagonal blocks | diagonal"""
+        b0, b1 = self.blocks(p)
+        w = (b1 - b0) * TILE
+        return (self.npad - b0 * TILE) * w + (b1 - b0) * TILE * TILE + w
+
 
 def panel_cholesky(ops, layout, rank, comm):
-    """Right-looking panel Cholesky with look-ahead; returns when this rank's `ops` holds the complete factor.
+    """Right-looking panel Cholesky with look-ahead; returns the agreed info word (0 = ok, > 0 = 1-based failing column)
+    when this rank's `ops` holds the complete factor.
 
-    ops : build_panel(p), factor_panel(p), update_panel(q, p), pack_panel(p) -> list of contiguous tensors,
-          recv_buffers(p) -> list of tensors of the same shapes, unpack_panel(p, bufs)
-    comm: broadcast(tensors, src) -> object with .wait()   (asynchronous)
+    ops : build_panel(p)                      assemble an owned panel
+          factor_panel(p, prev)               owner: apply panel `prev` (or None) to panel p, factor it, fill and return its message buffer
+          recv_buffer(p)                      non-owner: the buffer panel p's message is received into
+          adopt_panel(p, buf, work)           everyone, once per panel, in order: `work.wait()` and make the panel the update operand
+          update_panels(qs, p)                apply panel p to the owned panels qs (ascending)
+          finish()                            -> this rank's info word
+    comm: broadcast(buf, src, ops) -> work with .wait()   (asynchronous; posted by every rank in panel order)
+          max_int(v) -> the maximum of v over the ranks
     """
     P = layout.npanels
     mine = layout.owned(rank)
     for p in mine:
         ops.build_panel(p)
 
-    def post(p):
-        """owner: factor + pack; everyone: post the (asynchronous) broadcast of panel p."""
+    def post(p, prev):
+        """owner: (update with `prev`,) factor, pack; everyone: post the asynchronous broadcast of panel p."""
         src = layout.owner(p)
-        if src == rank:
-            ops.factor_panel(p)
-            bufs = ops.pack_panel(p)
-        else:
-            bufs = ops.recv_buffers(p)
-        return bufs, comm.broadcast(bufs, src)
+        buf = ops.factor_panel(p, prev) if src == rank else ops.recv_buffer(p)
+        return buf, comm.broadcast(buf, src, ops)
 
-    inflight = post(0)
+    inflight = post(0, None)
     for p in range(P):
-        bufs, work = inflight
-        work.wait()
-        if layout.owner(p) != rank:
-            ops.unpack_panel(p, bufs)
+        buf, work = inflight
+        ops.adopt_panel(p, buf, work)
         nxt = p + 1
         if nxt < P:
-            if layout.owner(nxt) == rank:
-                ops.update_panel(nxt, p)          # the next panel first ...
-            inflight = post(nxt)                  # ... so its factorisation + broadcast overlap with the rest
-        for q in mine:
-            if q > nxt:
-                ops.update_panel(q, p)
-    ops.finish()
+            inflight = post(nxt, p)          # the owner of the next panel updates + factors it first, off the main stream
+        ops.update_panels([q for q in mine if q > nxt], p)
+    return comm.max_int(ops.finish())
 
 
 # ---------------------------------------------------------------------------------------------------
 # torch.distributed plumbing
 # ---------------------------------------------------------------------------------------------------
 class _Work(object):
-    def __init__(self, works):
+    def __init__(self, works, after=None):
         self.works = works
+        self.after = after
 
     def wait(self):
         for w in self.works:
-            w.wait()
+            if w is not None:
+                w.wait()
+        if self.after is not None:
+            self.after()
 
 
 class TorchComm(object):
-    def __init__(self, group=None):
+    """Panel broadcast over torch.distributed.  Messages of at least `split_bytes` travel as scatter + all-gather: the
+    source sends a different 1/R of the panel to every rank over its own link, then the ranks exchange their parts --
+    2 (R-1)/R of the message per link instead of the whole message hopping round a ring (xGMI is
+    point-to-point, a ring broadcast is per-link bound)."""
+
+    def __init__(self, group=None, split_bytes=8 << 20):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.split_bytes = split_bytes
 
-    def broadcast(self, tensors, src):
-        return _Work([self.dist.broadcast(t, src=src, group=self.group, async_op=True) for t in tensors])
+    def broadcast(self, buf, src, ops=None):
+        dist = self.dist
+        ctx = ops.comm_stream_context(src == self.rank) if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
+        with ctx:
+            n = buf.numel()
+            if self.world == 1:
+                return _Work([])
+            if n * buf.element_size() < self.split_bytes or n % self.world:
+                return _Work([dist.broadcast(buf, src=src, group=self.group, async_op=True)])
+            parts = list(buf.view(self.world, n // self.world).unbind(0))
+            mine = parts[self.rank]
+            if dist.get_backend(self.group) == "nccl":
+                # both collectives are queued on RCCL's stream in this order; in-place all-gather of the rank's own part
+                w1 = dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
+                return _Work([w1, w2])
+            # CPU backends (gloo rehearsal) do not order two asynchronous collectives: run them one after the other
+            dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group)
+            return _Work([dist.all_gather(parts, mine.clone(), group=self.group, async_op=True)])
+
+    def max_int(self, v):
+        import torch
+        dev = "cuda" if self.dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([int(v)], dtype=torch.int64, device=dev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+
+class _NullContext(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 class HostStagedComm(object):
@@ -124,41 +177,64 @@ class HostStagedComm(object):
         self.dist = dist
         self.group = group
 
-    def broadcast(self, tensors, src):
+    def broadcast(self, buf, src, ops=None):
         comm = self
 
         class _W(object):
             def wait(self_w):
-                for t in tensors:
-                    h = t.detach().cpu().contiguous()
-                    comm.dist.broadcast(h, src=src, group=comm.group)
-                    if comm.dist.get_rank(comm.group) != src:
-                        t.copy_(h)
+                if ops is not None and hasattr(ops, "sync_for_host"):
+                    ops.sync_for_host()
+                h = buf.detach().cpu().contiguous()
+                comm.dist.broadcast(h, src=src, group=comm.group)
+                if comm.dist.get_rank(comm.group) != src:
+                    buf.copy_(h)
         return _W()
+
+    def max_int(self, v):
+        import torch
+        t = torch.tensor([int(v)], dtype=torch.int64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
 
 
 # ---------------------------------------------------------------------------------------------------
 # product ops: libgpx kernels on this rank's GPU
 # ---------------------------------------------------------------------------------------------------
 class GpxOps(object):
-    def __init__(self, x_dev, theta, layout, device):
+    """Two streams per rank: `main` (the caller's current stream) carries the trailing updates, `side` (high priority)
+    the critical path of the NEXT panel -- its update, factorisation, packing and, on its owner, the broadcast post --
+    plus the copies of received panels into L.  Two staging buffers hold the messages of panels p and p+1; events order
+    every reuse of a buffer behind its last readers on both streams."""
+
+    def __init__(self, x_dev, theta, layout, device, rank=0, jitter=0.0):
         import torch
         from . import _gpx
         self.torch, self._gpx, self.lib = torch, _gpx, _gpx.lib
         self.layout = layout
+        self.rank = rank
         self.x = x_dev                                  # [n, d] float64 on `device`
         self.n, self.d = x_dev.shape
         self.theta = np.ascontiguousarray(theta, dtype=np.float64)
         with np.errstate(divide="ignore"):
-            self.vt = float(np.exp(self.theta[1]))
+            self.vt = float(np.exp(self.theta[1])) + jitter
+        self.jitter = jitter
         npad, nblk = layout.npad, layout.nblk
         self.L = torch.empty((npad, npad), dtype=torch.float64, device=device)
         self.Dinv = torch.empty((nblk, TILE, TILE), dtype=torch.float64, device=device)
         self.diag = torch.empty(npad, dtype=torch.float64, device=device)
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
+        self.main = torch.cuda.current_stream(device)
+        self.side = torch.cuda.Stream(device=device, priority=-1)
+        self.stage = [torch.empty(layout.message_elems(0), dtype=torch.float64, device=device) for _ in range(2)]
+        self._operand = {}                              # panel -> (device pointer, leading dimension, first row) of its update operand
+        self._ev_avail = {}                             # panel -> event: message complete (recorded on main)
+        self._ev_main_done = {}                         # panel -> event: main's updates with that panel are queued
+        self._ev_side_done = [None, None]               # slot -> event: side stream is done reading the slot
+        self._side_has_work = False
 
-    def _stream(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+    # ---- helpers ------------------------------------------------------------------------------
+    def _stream_ptr(self, st):
+        return ctypes.c_void_p(st.cuda_stream)
 
     @staticmethod
     def _p(t, byte_offset=0):
@@ -167,59 +243,152 @@ class GpxOps(object):
     def _Lptr(self, row, col):
         return ctypes.c_void_p(self.L.data_ptr() + 8 * (row * self.layout.npad + col))
 
+    def _geom(self, p):
+        b0, b1 = self.layout.blocks(p)
+        return b0, b1, b0 * TILE, (b1 - b0) * TILE, self.layout.npad - b0 * TILE     # blocks, first column, width, rows
+
+    def _slot(self, p):
+        return self.stage[p % 2][:self.layout.message_elems(p)]
+
+    def _split(self, p, buf):
+        b0, b1, c0, w, rows = self._geom(p)
+        a = rows * w
+        b = a + (b1 - b0) * TILE * TILE
+        return buf[:a].view(rows, w), buf[a:b].view(b1 - b0, TILE, TILE), buf[b:b + w]
+
+    def comm_stream_context(self, is_source):
+        """the stream a broadcast is posted from: the side stream on the panel's owner (the message is packed there),
+        the main stream elsewhere (ordered behind the last updates that read the receive buffer)"""
+        return self.torch.cuda.stream(self.side if is_source and self._side_has_work else self.main)
+
+    def sync_for_host(self):
+        self.side.synchronize()
+        self.main.synchronize()
+
+    # ---- the ops interface ----------------------------------------------------------------------
     def build_panel(self, p):
         """Gram columns of panel p, rows from its diagonal down (+vt on the diagonal, identity padding)."""
-        b0, b1 = self.layout.blocks(p)
-        c0, c1 = b0 * TILE, b1 * TILE
+        b0, b1, c0, w, rows = self._geom(p)
         n, d, npad = self.n, self.d, self.layout.npad
         if c0 >= n:      # panel entirely in the padding: identity
-            self.L[c0:, c0:c1].zero_()
-            self.L[c0:c1, c0:c1].fill_diagonal_(1.0)
+            self.L[c0:, c0:c0 + w].zero_()
+            self.L[c0:c0 + w, c0:c0 + w].fill_diagonal_(1.0)
             return
         xi = ctypes.c_void_p(self.x.data_ptr() + 8 * c0 * d)
-        st = self.lib.gpx_dev_gram(xi, n - c0, xi, min(c1, n) - c0, d, self._gpx.ptr(self.theta), self.vt, 0, 1,
-                                   self._Lptr(c0, c0), npad, npad - c0, c1 - c0, self._stream())
+        st = self.lib.gpx_dev_gram(xi, n - c0, xi, min(c0 + w, n) - c0, d, self._gpx.ptr(self.theta), self.vt, 0, 1,
+                                   self._Lptr(c0, c0), npad, npad - c0, w, self._stream_ptr(self.main))
         self._gpx.check(st, "gpx_dev_gram(panel %d)" % p)
 
-    def factor_panel(self, p):
-        b0, b1 = self.layout.blocks(p)
-        st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
-                                         self._p(self.diag), self._p(self.info), self._stream())
-        self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
-
-    def update_panel(self, q, p):
-        """C[rows >= q0, panel q] -= L[rows >= q0, panel p] L[panel-q rows, panel p]^T"""
-        pb0, pb1 = self.layout.blocks(p)
-        qb0, qb1 = self.layout.blocks(q)
+    def _gemm(self, q0, q1, p, stream):
+        """C[rows >= q0, columns q0..q1) -= P[rows >= q0] P[rows q0..q1)^T with P = the update operand of panel p"""
+        ptr, ld, first = self._operand[p]
         npad = self.layout.npad
-        r0 = qb0 * TILE
-        A = self._Lptr(r0, pb0 * TILE)
-        C = self._Lptr(r0, r0)
-        st = self.lib.gpx_dev_gemm_nt(A, npad, A, npad, C, npad, npad - r0, (qb1 - qb0) * TILE, (pb1 - pb0) * TILE,
-                                      -1.0, 1.0, 0, self._stream())
-        self._gpx.check(st, "panel update (%d <- %d)" % (q, p))
+        _b0, _b1, _c0, wp, _rows = self._geom(p)
+        A = ctypes.c_void_p(ptr + 8 * (q0 - first) * ld)
+        lower = 1 if q1 == npad else 0            # the run reaches the last column: square, lower tiles only (the bulk SYRK)
+        st = self.lib.gpx_dev_gemm_nt(A, ld, A, ld, self._Lptr(q0, q0), npad, npad - q0, q1 - q0, wp, -1.0, 1.0, lower,
+                                      self._stream_ptr(stream))
+        self._gpx.check(st, "panel update (columns %d..%d <- panel %d)" % (q0, q1, p))
 
-    def _panel_views(self, p):
-        b0, b1 = self.layout.blocks(p)
-        return self.L[b0 * TILE:, b0 * TILE:b1 * TILE], self.Dinv[b0:b1], self.diag[b0 * TILE:b1 * TILE]
+    def factor_panel(self, p, prev):
+        b0, b1, c0, w, rows = self._geom(p)
+        torch = self.torch
+        self._side_has_work = True
+        with torch.cuda.stream(self.side):
+            if prev is not None:
+                self.side.wait_event(self._ev_avail[prev])        # panel `prev` has arrived
+                self._gemm(c0, c0 + w, prev, self.side)
+            else:
+                self.side.wait_stream(self.main)                  # the panel has been assembled on the main stream
+            st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
+                                             self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
+            self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
+            buf = self._slot(p)
+            if self.layout.world > 1:
+                # pack: the slot's previous panel (p - 2) must have been read by the main stream's updates
+                if p - 2 in self._ev_main_done:
+                    self.side.wait_event(self._ev_main_done[p - 2])
+                panel, dinv, diag = self._split(p, buf)
+                panel.copy_(self.L[c0:, c0:c0 + w])
+                dinv.copy_(self.Dinv[b0:b1])
+                diag.copy_(self.diag[c0:c0 + w])
+        # the owner's own updates read the panel in place
+        self._operand[p] = (self.L.data_ptr() + 8 * (c0 * self.layout.npad + c0), self.layout.npad, c0)
+        return buf
 
-    def pack_panel(self, p):
-        panel, dinv, diag = self._panel_views(p)
-        return [panel.contiguous(), dinv, diag]        # dinv / diag slices are already contiguous
+    def recv_buffer(self, p):
+        # posted from the main stream: ordered behind main's reads of this slot (panel p - 2); the side stream's reads
+        # of it (copy into L, update of an owned next panel) are joined explicitly
+        ev = self._ev_side_done[p % 2]
+        if ev is not None:
+            self.main.wait_event(ev)
+        self._side_has_work = False
+        return self._slot(p)
 
-    def recv_buffers(self, p):
-        panel, dinv, diag = self._panel_views(p)
-        return [self.torch.empty(panel.shape, dtype=panel.dtype, device=panel.device), dinv, diag]
+    def adopt_panel(self, p, buf, work):
+        torch = self.torch
+        b0, b1, c0, w, rows = self._geom(p)
+        with torch.cuda.stream(self.main):
+            work.wait()                                           # main stream waits for the message (no host block on RCCL)
+            if self.layout.owner(p) == self.rank:
+                self.main.wait_stream(self.side)                  # factorisation (and pack) of the own panel
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        self._ev_avail[p] = ev
+        if self.layout.owner(p) != self.rank:
+            panel, dinv, diag = self._split(p, buf)
+            self._operand[p] = (panel.data_ptr(), w, c0)
+            # copy into this rank's L / Dinv / diag on the side stream: needed for the complete factor only
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.L[c0:, c0:c0 + w].copy_(panel)
+                self.Dinv[b0:b1].copy_(dinv)
+                self.diag[c0:c0 + w].copy_(diag)
 
-    def unpack_panel(self, p, bufs):
-        panel, _dinv, _diag = self._panel_views(p)
-        panel.copy_(bufs[0])
+    def update_panels(self, qs, p):
+        # consecutive owned panels form one launch (world size 1: all of them = the single bulk SYRK of csrc/chol.hip)
+        runs = []
+        for q in qs:
+            _b0, _b1, c0, w, _rows = self._geom(q)
+            if runs and runs[-1][1] == c0:
+                runs[-1][1] = c0 + w
+            else:
+                runs.append([c0, c0 + w])
+        for q0, q1 in runs:
+            self._gemm(q0, q1, p, self.main)
+        ev = self.torch.cuda.Event()
+        ev.record(self.main)
+        self._ev_main_done[p] = ev
+        es = self.torch.cuda.Event()
+        es.record(self.side)
+        self._ev_side_done[p % 2] = es
+        self._operand.pop(p - 2, None)
 
     def finish(self):
-        self.torch.cuda.current_stream().synchronize()
-        info = int(self.info.item())
-        if info > 0:
-            raise np.linalg.LinAlgError("covariance matrix not positive definite (leading minor %d)" % info)
+        self.side.synchronize()
+        self.main.synchronize()
+        return int(self.info.item())
+
+
+def combine_approx_partials(o, Sigma, v, vt):
+    """(mean without meant, variance, sigma2, rest) of UncertaintyPropagationApprox.propagate_GA from the summed partials of
+    gpx_propagate_approx_rows (skgpuppy/UncertaintyPropagation.py:397-479): o = [beta.C, beta.tr, C.KinvC, KinvC.tr,
+    (J_k.KinvJ_k, beta.J_k) for every k]."""
+    o = np.asarray(o, dtype=np.float64)
+    S = np.asarray(Sigma, dtype=np.float64)
+    d = S.shape[0]
+    mu = o[0] + 0.5 * o[1]
+    s2 = (v + vt) - o[2]
+    var2 = -sum(S[k, k] * (o[4 + 2 * k] - o[5 + 2 * k] ** 2) for k in range(d))
+    var3 = -o[3]
+    return mu, s2 + var2 + var3, s2, var2 + var3
+
+
+def row_shards(n, world):
+    """[lo, hi) per rank: 128-aligned row panels of (almost) equal height"""
+    nblk = (n + TILE - 1) // TILE
+    per = (nblk + world - 1) // world
+    return [(min(n, r * per * TILE), min(n, (r + 1) * per * TILE)) for r in range(world)]
 
 
 class ShardedGaussianProcess(object):
@@ -234,6 +403,10 @@ class ShardedGaussianProcess(object):
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        # libgpx works on the calling thread's gpx_set_device choice: bind it to this rank's GPU
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _gpx.check(_gpx.lib.gpx_set_device(idx), "gpx_set_device")
+        self._on_device = dist.get_backend(group) == "nccl"       # collectives on device tensors (RCCL has no host path)
         self.x = x
         self.n, self.d = np.shape(x)
         self.meant = np.mean(t)
@@ -245,19 +418,31 @@ class ShardedGaussianProcess(object):
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = None
         self._h = ctypes.c_void_p()
+        self.jitter = 0.0
         self.refit()
 
     def refit(self):
-        """(re)run the sharded fit on the resident inputs -- one benchmark `fit` step."""
+        """(re)run the sharded fit on the resident inputs -- one benchmark `fit` step.  A non-positive pivot anywhere is
+        seen by every rank (max of the info words) and answered by ONE collective retry on K + 1e-5 I, the reference's
+        fallback (skgpuppy/Covariance.py:180-185); if that fails too every rank raises LinAlgError."""
+        import torch
         from . import _gpx
         self.close()
-        ops = GpxOps(self._x_dev, self.theta_min, self.layout, self.device)
-        panel_cholesky(ops, self.layout, self.rank, self._comm)
-        self._ops = ops
-        st = _gpx.lib.gpx_adopt_factor(ctypes.c_void_p(self._x_dev.data_ptr()), ctypes.c_void_p(self._t_dev.data_ptr()),
-                                       self.n, self.d, _gpx.ptr(self.theta_min), ops._p(ops.L), ops._p(ops.Dinv),
-                                       ops._p(ops.diag), 0.0, None, ctypes.byref(self._h))
-        _gpx.check(st, "gpx_adopt_factor")
+        with torch.cuda.device(self.device):
+            for jitter in (0.0, JITTER):
+                ops = GpxOps(self._x_dev, self.theta_min, self.layout, self.device, rank=self.rank, jitter=jitter)
+                info = panel_cholesky(ops, self.layout, self.rank, self._comm)
+                if info == 0:
+                    break
+                del ops
+            if info > 0:
+                raise np.linalg.LinAlgError("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter" % info)
+            self._ops = ops
+            self.jitter = jitter
+            st = _gpx.lib.gpx_adopt_factor(ctypes.c_void_p(self._x_dev.data_ptr()), ctypes.c_void_p(self._t_dev.data_ptr()),
+                                           self.n, self.d, _gpx.ptr(self.theta_min), ops._p(ops.L), ops._p(ops.Dinv),
+                                           ops._p(ops.diag), jitter, None, ctypes.byref(self._h))
+            _gpx.check(st, "gpx_adopt_factor")
 
     def close(self):
         if getattr(self, "_h", None):
@@ -277,6 +462,16 @@ class ShardedGaussianProcess(object):
         lo = min(m, self.rank * per)
         return lo, min(m, lo + per)
 
+    def _all_gather(self, mine):
+        """all-gather of equally shaped device tensors; the result comes back on the host.  With RCCL every operand stays
+        on the GPU (RCCL has no CPU path); a CPU backend (gloo rehearsal) gets host tensors."""
+        import torch
+        import torch.distributed as dist
+        send = mine if self._on_device else mine.cpu()
+        gathered = [torch.empty_like(send) for _ in range(self.world)]
+        dist.all_gather(gathered, send, group=self.group)
+        return [g.cpu() for g in gathered]
+
     def estimate_local(self, xs_dev, mean_dev, var_dev):
         """predict this rank's resident query shard (device tensors, mean WITHOUT meant)."""
         from . import _gpx
@@ -289,7 +484,6 @@ class ShardedGaussianProcess(object):
         """Same contract as GaussianProcess.estimate_many (skgpuppy/GaussianProcess.py:68-80); every rank returns
         the full arrays (query shards are all-gathered)."""
         import torch
-        import torch.distributed as dist
         from . import _gpx
         xs = _gpx.f64(np.array(x_stars))
         m = xs.shape[0]
@@ -299,18 +493,14 @@ class ShardedGaussianProcess(object):
         if hi > lo:
             xs_dev = torch.as_tensor(xs[lo:hi]).to(self.device)
             self.estimate_local(xs_dev, out[0, :hi - lo], out[1, :hi - lo])
-        host = out.cpu()                                  # small (2 x m/R doubles): gathered on the host backend-agnostically
-        gathered = [torch.empty_like(host) for _ in range(self.world)]
-        dist.all_gather(gathered, host, group=self.group)
-        full = torch.cat(gathered, dim=1).numpy()[:, :m]
+        full = torch.cat(self._all_gather(out), dim=1).numpy()[:, :m]
         return full[0] + self.meant, full[1]
 
-
-    # ---- uncertainty propagation on the replicated factor (last row) ------------------------
+    # ---- uncertainty propagation (last row) ------------------------------------------------------
     def propagate_GA(self, u, Sigma):
         """UncertaintyPropagationApprox.propagate_GA on this rank's copy of the factor
         (skgpuppy/UncertaintyPropagation.py:381-523): every rank holds the complete L after the panel broadcasts, so a
-        single propagation needs no exchange at all -- it runs as two triangular solves on the right-hand-side block
+        single propagation needs no exchange at all -- it runs as two triangular sweeps on the right-hand-side block
         (no K^-1: 34 GB at N = 65536 stay unallocated).  Returns (mean + meant, variance)."""
         from . import _gpx
         u = _gpx.f64(u)
@@ -320,11 +510,33 @@ class ShardedGaussianProcess(object):
                    "gpx_propagate_approx")
         return out[0].value + self.meant, out[1].value
 
+    def propagate_GA_sharded(self, u, Sigma):
+        """ONE propagation shared by all ranks (collective): rank r passes over its row panel of K^-1 only -- (K^-1 v)_i
+        and every quadratic form of skgpuppy/UncertaintyPropagation.py:412-479 are sums over the rows -- and the 4 + 2 d
+        partial sums meet in one all-reduce.  K^-1 is materialised per rank on first use, so this is the path for MANY
+        propagations on one fit (inverse propagation, design studies): each call then reads 1/R of K^-1 per GPU."""
+        import torch
+        import torch.distributed as dist
+        from . import _gpx
+        u = _gpx.f64(u)
+        S = _gpx.f64(Sigma)
+        lo, hi = row_shards(self.n, self.world)[self.rank]
+        part = np.zeros(4 + 2 * self.d)
+        _gpx.check(_gpx.lib.gpx_propagate_approx_rows(self._h, _gpx.ptr(u), _gpx.ptr(S), lo, hi, _gpx.ptr(part)),
+                   "gpx_propagate_approx_rows")
+        tot = torch.as_tensor(part)
+        if self._on_device:
+            tot = tot.to(self.device)
+        if self.world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        mu, var, _s2, _rest = combine_approx_partials(tot.cpu().numpy(), S, float(np.exp(self.theta_min[0])),
+                                                      float(np.exp(self.theta_min[1])))
+        return mu + self.meant, var
+
     def propagate_many(self, us, Sigmas):
         """many independent propagations (the inverse-propagation and design-study workload): the CALLS are sharded
         across the ranks, results all-gathered -- one small collective for the whole batch."""
         import torch
-        import torch.distributed as dist
         us = np.asarray(us, dtype=np.float64)
         k = us.shape[0]
         lo, hi = self.shard(k)
@@ -332,9 +544,7 @@ class ShardedGaussianProcess(object):
         mine = torch.zeros((per, 2), dtype=torch.float64)
         for i in range(lo, hi):
             mine[i - lo, 0], mine[i - lo, 1] = self.propagate_GA(us[i], Sigmas[i])
-        gathered = [torch.empty_like(mine) for _ in range(self.world)]
-        dist.all_gather(gathered, mine.to(self.device) if dist.get_backend(self.group) == "nccl" else mine, group=self.group)
-        full = torch.cat([g.cpu() for g in gathered], dim=0).numpy()[:k]
+        full = torch.cat(self._all_gather(mine.to(self.device)), dim=0).numpy()[:k]
         return full[:, 0], full[:, 1]
 
 

@@ -19,9 +19,10 @@ from oracle import oracle as orc  # noqa: E402
 class CpuOps(object):
     """Reference implementation of the ops interface on CPU tensors (test infrastructure)."""
 
-    def __init__(self, x, theta, layout):
-        self.layout, self.x, self.theta = layout, x, theta
+    def __init__(self, x, theta, layout, rank):
+        self.layout, self.x, self.theta, self.rank = layout, x, theta, rank
         npad = layout.npad
+        self.stage = [torch.empty(npad * layout.pb * TILE, dtype=torch.float64) for _ in range(2)]   # two message slots
         self.L = torch.full((npad, npad), float("nan"), dtype=torch.float64)   # NaN: unbuilt regions must never be read
         self.calls = []
 
@@ -45,7 +46,9 @@ class CpuOps(object):
         self.L[b0 * TILE:, b0 * TILE:b1 * TILE] = self._K(rows, cols)
         self.calls.append(("build", p))
 
-    def factor_panel(self, p):
+    def factor_panel(self, p, prev):
+        if prev is not None:
+            self._update(p, prev)
         b0, b1 = self.layout.blocks(p)
         c0, c1 = b0 * TILE, b1 * TILE
         D = torch.linalg.cholesky(torch.tril(self.L[c0:c1, c0:c1]) + torch.tril(self.L[c0:c1, c0:c1], -1).T)
@@ -53,8 +56,11 @@ class CpuOps(object):
         if c1 < self.layout.npad:
             self.L[c1:, c0:c1] = torch.linalg.solve_triangular(D, self.L[c1:, c0:c1].T, upper=False).T
         self.calls.append(("factor", p))
+        buf = self.stage[p % 2][:self._view(p).numel()]
+        buf.copy_(self._view(p).reshape(-1))
+        return buf
 
-    def update_panel(self, q, p):
+    def _update(self, q, p):
         pb0, pb1 = self.layout.blocks(p)
         qb0, qb1 = self.layout.blocks(q)
         r0 = qb0 * TILE
@@ -64,21 +70,24 @@ class CpuOps(object):
         self.L[r0:, r0:qb1 * TILE] -= A @ B.T
         self.calls.append(("update", q, p))
 
+    def update_panels(self, qs, p):
+        for q in qs:
+            self._update(q, p)
+
     def _view(self, p):
         b0, b1 = self.layout.blocks(p)
         return self.L[b0 * TILE:, b0 * TILE:b1 * TILE]
 
-    def pack_panel(self, p):
-        return [self._view(p).contiguous()]
+    def recv_buffer(self, p):
+        return self.stage[p % 2][:self._view(p).numel()]
 
-    def recv_buffers(self, p):
-        return [torch.empty(self._view(p).shape, dtype=torch.float64)]
-
-    def unpack_panel(self, p, bufs):
-        self._view(p).copy_(bufs[0])
+    def adopt_panel(self, p, buf, work):
+        work.wait()
+        if self.layout.owner(p) != self.rank:
+            self._view(p).copy_(buf.view(self._view(p).shape))
 
     def finish(self):
-        pass
+        return 0
 
 
 def main():
@@ -89,8 +98,10 @@ def main():
     x = rng.uniform(0, 5, (n, d))
     theta = np.log(np.array([1.5, 0.05, 0.3, 0.2, 0.4]))
     layout = PanelLayout(n, world, panel_blocks=pb)
-    ops = CpuOps(x, theta, layout)
-    panel_cholesky(ops, layout, rank, TorchComm())
+    ops = CpuOps(x, theta, layout, rank)
+    # split_bytes=1: every message whose length the world size divides travels as scatter + all-gather
+    info = panel_cholesky(ops, layout, rank, TorchComm(split_bytes=1 if len(sys.argv) > 3 and sys.argv[3] == "split" else 1 << 40))
+    assert info == 0
     with np.errstate(divide="ignore"):
         K = orc.gram(x, theta)
     Lref = np.linalg.cholesky(K)

@@ -51,6 +51,15 @@ def main():
             ok = ok and abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9
             ok = ok and abs(pm[i] - owant[0]) < 1e-8 and abs(pv[i] - owant[1]) < 2e-8
         print("sharded propagate_many vs single-GPU and oracle:", ok)
+    # ONE propagation shared by the ranks: row panels of K^-1, 4 + 2 d partial sums, one all-reduce (last row)
+    for i in (0, 3):
+        sm, sv = gp.propagate_GA_sharded(us[i], Ss[i])
+        if rank == 0:
+            owant = orc.approx_propagate(og_, us[i], Ss[i])
+            ok = ok and abs(sm - pm[i]) < 1e-9 and abs(sv - pv[i]) < 1e-9
+            ok = ok and abs(sm - owant[0]) < 1e-8 and abs(sv - owant[1]) < 2e-8
+    if rank == 0:
+        print("row-sharded propagate_GA vs call-sharded and oracle:", ok)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     gp.close()

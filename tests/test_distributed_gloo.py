@@ -8,12 +8,12 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.mark.parametrize("n,pb,world", [(700, 1, 2), (1000, 2, 2), (390, 1, 3)])
-def test_panel_cholesky_gloo(n, pb, world):
+@pytest.mark.parametrize("n,pb,world,mode", [(700, 1, 2, "bcast"), (1000, 2, 2, "split"), (390, 1, 3, "split"), (900, 1, 2, "split")])
+def test_panel_cholesky_gloo(n, pb, world, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(29600 + n % 97),
-           os.path.join(ROOT, "tests", "_gloo_worker.py"), str(n), str(pb)]
+           os.path.join(ROOT, "tests", "_gloo_worker.py"), str(n), str(pb), mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "max |L - Lref|" in r.stdout
@@ -28,3 +28,39 @@ def test_layout_ownership():
     lay = PanelLayout(1000, 3, panel_blocks=2)
     assert lay.npad == 1024 and lay.npanels == 4 and lay.blocks(3) == (6, 8)
     assert [lay.owner(p) for p in range(4)] == [0, 1, 2, 0]
+
+
+def test_row_shards_and_partial_combination():
+    """Host side of the row-sharded Approx propagation (last row): the shards tile [0, n) in 128-aligned
+    panels, and partial sums over the shards -- computed here from the oracle's K^-1 -- combine to the oracle's
+    propagate_GA (the device side of the same partials is covered by the -m gpu two-rank test)."""
+    import numpy as np
+    from oracle import oracle as orc
+    from skgpuppy_amd.distributed import combine_approx_partials, row_shards
+    for n, world in ((1000, 3), (128, 2), (16384, 8), (5, 4)):
+        sh = row_shards(n, world)
+        assert sh[0][0] == 0 and sh[-1][1] == n and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+        assert all((lo % 128 == 0 or lo == n) and (hi % 128 == 0 or hi == n) for lo, hi in sh)
+    rng = np.random.RandomState(5)
+    n, d = 300, 3
+    x = rng.uniform(0, 10, (n, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(n)
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    og = orc.OracleGP(x, t, theta)
+    u = np.array([5.0, 4.0, 6.0])
+    S = np.diag([0.01, 0.02, 0.005])
+    C, J, H = orc.cjh(og, u)
+    J = J.reshape(n, d)
+    tr = np.einsum("iab,ba->i", H.reshape(n, d, d), S)
+    beta = og.beta()
+    tot = np.zeros(4 + 2 * d)
+    for lo, hi in row_shards(n, 3):
+        r = slice(lo, hi)
+        KC = og.Kinv[r].dot(C)
+        part = [beta[r].dot(C[r]), beta[r].dot(tr[r]), C[r].dot(KC), KC.dot(tr[r])]
+        for k in range(d):
+            part += [J[r, k].dot(og.Kinv[r].dot(J[:, k])), beta[r].dot(J[r, k])]
+        tot += np.array(part)
+    mu, var, _s2, _rest = combine_approx_partials(tot, S, np.exp(theta[0]), np.exp(theta[1]))
+    om, ov = orc.approx_propagate(og, u, S)
+    assert mu + og.meant == pytest.approx(om, abs=1e-10) and var == pytest.approx(ov, abs=1e-9)

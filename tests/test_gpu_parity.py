@@ -458,6 +458,55 @@ def test_sharded_fit_two_ranks_share_one_gpu(N, d):
     assert "sharded vs single-GPU" in r.stdout
 
 
+def test_sharded_collectives_on_rccl_world_size_one():
+    """The public collectives of ShardedGaussianProcess on a real RCCL (nccl) group -- RCCL has no host path, so every
+    operand of all_gather / all_reduce must live on the device (one rank is all this box offers; the two-rank run above
+    goes through gloo).  Also: a K that needs the reference's +1e-5 jitter gets it collectively on the sharded path."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "scikit-gpuppy_amd"))
+import skgpuppy_amd as sk
+from skgpuppy_amd.distributed import ShardedGaussianProcess
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+rng = np.random.RandomState(3)
+N, d = 1500, 3
+x = rng.uniform(0, 10, (N, d)); t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N); xs = rng.uniform(0, 10, (77, d))
+theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+gp = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0))
+ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+m, v = gp.estimate_many(xs); m1, v1 = ref.estimate_many(xs)
+assert np.abs(m - m1).max() < 1e-10 and np.abs(v - v1).max() < 1e-10
+us = np.array([[5.0] * d, x[7]]); Ss = [0.01 * np.eye(d)] * 2
+pm, pv = gp.propagate_many(us, Ss)
+up = sk.UncertaintyPropagationApprox(ref)
+for i in range(2):
+    want = up.propagate_GA(us[i], Ss[i])
+    got = gp.propagate_GA_sharded(us[i], Ss[i])
+    assert abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9 and abs(got[0] - want[0]) < 1e-9 and abs(got[1] - want[1]) < 1e-9
+gp.close()
+# a tight cluster with vt = 0: K is numerically indefinite -> the single-GPU fit takes the +1e-5 jitter, and so must the sharded one
+xd = rng.uniform(0, 1e-4, (600, d)); td = rng.randn(600); xs = rng.uniform(0, 1e-4, (77, d))
+th2 = np.array([0.0, -np.inf] + [0.0] * d)
+one = sk.GaussianProcess(xd, td, sk.GaussianCovariance(), th2.copy())
+assert one._dev().jitter() == 1e-5
+sh = ShardedGaussianProcess(xd, td, th2, device=torch.device("cuda", 0))
+assert sh.jitter == 1e-5
+ms, vs = sh.estimate_many(xs); mo, vo = one.estimate_many(xs)
+assert np.allclose(ms, mo, rtol=0, atol=1e-8) and np.allclose(vs, vo, rtol=0, atol=1e-8)
+sh.close(); dist.destroy_process_group(); print("RCCL world-size-1 collectives ok")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "collectives ok" in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------
 # "next" row f1: hyper-parameter likelihood, gradient and ML estimate
 # ------------------------------------------------------------------------------------------------
