@@ -31,6 +31,31 @@ void gpx_set_error(const char *fmt, ...);
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// ---- exp for non-positive arguments (every exponent on the path is -1/2 of a squared distance, or a sum of such) ----
+// Plain Cody-Waite: n = rint(x log2 e), r = x - n ln2 (two-term), degree-12 Taylor polynomial on |r| <= ln2/2
+// (truncation 1.7e-16), scaled by v_ldexp_f64 (which also produces the denormal / zero results for very negative x).
+// ~18 fp64 ops instead of the ~45 of the generic exp; within 2 ulp of it.
+static __device__ __forceinline__ double exp_nonpos(double x)
+{
+    x = fmax(x, -750.0);
+    const double n = rint(x * 1.4426950408889634);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;          // 1/12!
+    p = fma(p, r, 2.50521083854417187751e-08);      // 1/11!
+    p = fma(p, r, 2.75573192239858906526e-07);      // 1/10!
+    p = fma(p, r, 2.75573192239858906526e-06);      // 1/9!
+    p = fma(p, r, 2.48015873015873015873e-05);      // 1/8!
+    p = fma(p, r, 1.98412698412698412698e-04);      // 1/7!
+    p = fma(p, r, 1.38888888888888888889e-03);      // 1/6!
+    p = fma(p, r, 8.33333333333333333333e-03);      // 1/5!
+    p = fma(p, r, 4.16666666666666666667e-02);      // 1/4!
+    p = fma(p, r, 1.66666666666666666667e-01);      // 1/3!
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 // ---- per-kernel-class event profiler ---------------------------------------------------------
 struct Profiler {
     int level = 0;   // 0 off; 1 = only the dominant kernel (128x128-tile GEMM launches); 2 = every kernel class

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long gr = row0 + wave * 16 + r;
-        double k0 = v * exp(-0.5 * acc0[r]);
-        double k1 = v * exp(-0.5 * acc1[r]);
+        double k0 = v * exp_nonpos(-0.5 * acc0[r]);
+        double k1 = v * exp_nonpos(-0.5 * acc1[r]);
         if (gr == gc) k0 += add_diag;
         if (gr == gc + 1) k1 += add_diag;
         if (pad_mode != PAD_NONE) {

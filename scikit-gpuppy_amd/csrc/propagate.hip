@@ -126,16 +126,18 @@ __global__ __launch_bounds__(256) void kinv_pass_kernel(const double *__restrict
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < NC; ++c) acc[r][c] = 0.0;
-    for (long j = t; j < npad; j += 256) {
-        double v[NC];
+    // thread = two adjacent columns: 16-byte loads, 1 KiB per wave-instruction and row (npad is a multiple of 128)
+    for (long j = 2 * t; j < npad; j += 512) {
+        v2d k[R];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = (c < nc) ? V[(long)c * npad + j] : 0.0;
+        for (int r = 0; r < R; ++r) k[r] = *reinterpret_cast<const v2d *>(Kinv + (i0 + r) * ld + j);
+        v2d v[NC];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const double k = Kinv[(i0 + r) * ld + j];
+        for (int c = 0; c < NC; ++c) v[c] = (c < nc) ? *reinterpret_cast<const v2d *>(V + (long)c * npad + j) : (v2d){0.0, 0.0};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) acc[r][c] = fma(k, v[c], acc[r][c]);
-        }
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) acc[r][c] = fma(k[r].y, v[c].y, fma(k[r].x, v[c].x, acc[r][c]));
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -244,31 +246,7 @@ __global__ __launch_bounds__(256) void exact_build_kernel(const double *__restri
 }
 
 // exp(x) for the pair kernel: x = e_i + e_j + b_i.a_j is <= ~0 by construction (it is the log of L_ij / (F_i F_j nc2),
-// a product of Gaussian factors), so only the plain Cody-Waite path is needed: n = rint(x log2 e), r = x - n ln2
-// (two-term), degree-12 Taylor polynomial on |r| <= ln2/2 (truncation 1.7e-16), scaled by v_ldexp_f64 (which also
-// produces the denormal / zero results for very negative x).  ~18 fp64 ops instead of the ~45 of the generic exp.
-__device__ __forceinline__ double exp_nonpos(double x)
-{
-    x = fmax(x, -750.0);
-    const double n = rint(x * 1.4426950408889634);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 2.08767569878680989792e-09;          // 1/12!
-    p = fma(p, r, 2.50521083854417187751e-08);      // 1/11!
-    p = fma(p, r, 2.75573192239858906526e-07);      // 1/10!
-    p = fma(p, r, 2.75573192239858906526e-06);      // 1/9!
-    p = fma(p, r, 2.48015873015873015873e-05);      // 1/8!
-    p = fma(p, r, 1.98412698412698412698e-04);      // 1/7!
-    p = fma(p, r, 1.38888888888888888889e-03);      // 1/6!
-    p = fma(p, r, 8.33333333333333333333e-03);      // 1/5!
-    p = fma(p, r, 4.16666666666666666667e-02);      // 1/4!
-    p = fma(p, r, 1.66666666666666666667e-01);      // 1/3!
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
-
+// a product of Gaussian factors), so exp_nonpos (common.h) serves.
 // S = sum_ij (Kinv_ij - beta_i beta_j) F_i F_j exp(e_i + e_j + b_i . a_j); the caller multiplies by nc2.
 // Kinv and L_ij are symmetric: only the pairs j <= i are visited (weight 2 off the diagonal), halving both the
 // HBM bytes (4 N^2) and the exp count of the reference's full double loop (UncertaintyPropagation2.pyx:173-179).
