@@ -394,6 +394,57 @@ def spgp_nll(x, t, theta, m):
             + np.log(ep).sum() / 2.0 + 0.5 * N * np.log(2 * np.pi))
 
 
+def spgp_nll_grad(x, t, theta, m):
+    """d spgp_nll / d theta in O(N M^2), theta = (log v, log vt, log w_1..d, pseudo-inputs row-major).
+
+    The reference's own gradient (Covariance.py:906-979) differentiates the dense N x N likelihood with O(N^2 M) work per
+    parameter and does not run on Python 3 (float index at :910, :970), so there is nothing to pin against: "gradient
+    parity unpinned".  This is the analytic derivative of the likelihood the reference minimises (Covariance.py:981-1019):
+    with Q = K_M + 1e-6 I, K = K_MN, Sigma = K^T Q^-1 K + diag(gamma), gamma_n = vt + v - (K^T Q^-1 K)_nn, alpha = Sigma^-1 y,
+    G = (Sigma^-1 - alpha alpha^T) / 2, g = diag G, H = G - diag(g):
+        d nll = 2 <P H, dK> - <P H P^T, dQ> + sum(g) (dv + dvt),   P = Q^-1 K,
+    everything expressed through the M x M matrix B = Q + K diag(1/gamma) K^T (Woodbury); the kernel derivatives then need
+    E = Kbar o K and F = Qbar o (Q - 1e-6 I) only through their row / column sums and E X, F Xb.  Checked against central
+    differences of spgp_nll in tests/test_oracle_golden.py; the GPU path (gpx_spgp_nll_grad) is checked against this."""
+    x = np.asarray(x, dtype=float)
+    N, d = x.shape
+    tg, xm = spgp_split(theta, d, m)
+    v, vt, w = unpack_theta(tg)
+    y = np.asarray(t, dtype=float)
+    Qk = gram_ij(xm, xm, tg)
+    K = gram_ij(xm, x, tg)                                      # [M, N]
+    L = cholesky(Qk + 1e-6 * np.eye(m), lower=True)
+    V = solve_triangular(L, K, lower=True)
+    gamma = vt + v - (V ** 2).sum(0)
+    A = vt * np.eye(m) + np.dot(V / gamma[None, :] * vt, V.T)   # = vt I + V D^-1 V^T, D = gamma / vt
+    Ainv = np.linalg.inv(A)
+    VD = V * (vt / gamma)[None, :]                              # V D^-1
+    T1 = np.dot(Ainv, VD)                                       # A^-1 V D^-1   [M, N]
+    betaA = np.dot(T1, y)
+    alpha = (y - np.dot(V.T, betaA)) / gamma
+    s_n = (T1 * V).sum(0)
+    g = 0.5 * ((1.0 - s_n) / gamma - alpha ** 2)
+    Vbar = T1 - np.outer(betaA, alpha) - 2.0 * V * g[None, :]
+    Kbar = solve_triangular(L, Vbar, lower=True, trans="T")     # L^-T Vbar
+    Qb = -0.5 * (np.eye(m) - vt * Ainv - np.outer(betaA, betaA)) + np.dot(V * g[None, :], V.T)
+    Qbar = solve_triangular(L, solve_triangular(L, Qb, lower=True, trans="T").T, lower=True, trans="T")   # L^-T Qb L^-1
+    Qbar = 0.5 * (Qbar + Qbar.T)
+    E = Kbar * K
+    F = Qbar * Qk
+    E1, Ec, EX = E.sum(1), E.sum(0), np.dot(E, x)
+    F1, FX = F.sum(1), np.dot(F, xm)
+    grad = np.empty(2 + d + m * d)
+    grad[0] = E.sum() + F.sum() + v * g.sum()
+    grad[1] = vt * g.sum()
+    for k in range(d):
+        qe = np.dot(xm[:, k] ** 2, E1) - 2.0 * np.dot(xm[:, k], EX[:, k]) + np.dot(x[:, k] ** 2, Ec)
+        qf = 2.0 * np.dot(xm[:, k] ** 2, F1) - 2.0 * np.dot(xm[:, k], FX[:, k])
+        grad[2 + k] = -0.5 * w[k] * (qe + qf)
+    dxb = -(xm * E1[:, None] - EX) * w[None, :] - 2.0 * (xm * F1[:, None] - FX) * w[None, :]
+    grad[2 + d:] = dxb.ravel()
+    return grad
+
+
 def spgp_nll_chunked(x, t, theta, m, chunk=32768):
     """spgp_nll (Covariance.py:981-1019) with the N-long contractions accumulated over column chunks of K_MN, so that
     BASELINE config 5 (N = 262144, M = 2048) needs ~1.5 GB of host memory instead of ~30 GB.  Same formula, same jitter;

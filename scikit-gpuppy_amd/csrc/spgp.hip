@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "common.h"
 
@@ -55,24 +56,24 @@ __global__ __launch_bounds__(256) void add_partials_kernel(double *__restrict__ 
     *reinterpret_cast<v2d *>(out + i) = acc;
 }
 
-// C (lower tiles) <- beta C + Wt Wt^T for the [mpad, npad] row-major Wt: the contraction runs over N = 262144 at BASELINE
+// C (lower tiles) <- beta C + alpha W W^T for a [mpad, npad] row-major W: the contraction runs over N = 262144 at BASELINE
 // config 5 while C has only 136 lower 128x128 tiles, so it is split into K-chunks that run concurrently on their own
 // streams (chunk 0 accumulates into C, the others into scratch) and are summed afterwards.
-static int spgp_wtw(gpx_spgp *h, double *C, double beta)
+static int spgp_wtw(gpx_spgp *h, const double *W, double *C, double beta, double alpha = 1.0)
 {
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad;
     int64_t chunk = round_up((np + gpx_spgp::SPLIT - 1) / gpx_spgp::SPLIT, TILE);
     const int nchunks = (int)((np + chunk - 1) / chunk);
     if (np < 16384 || nchunks < 2 || !h->split_buf)
-        return launch_gemm_nt(h->Wt, np, h->Wt, np, C, mp, mp, mp, np, 1.0, beta, 1, s, nullptr);
+        return launch_gemm_nt(W, np, W, np, C, mp, mp, mp, np, alpha, beta, 1, s, nullptr);
     GPX_HIP(hipEventRecord(h->split_ev[gpx_spgp::SPLIT], s));
     for (int c = 0; c < nchunks; ++c) {
         const int64_t k0 = c * chunk, kc = std::min<int64_t>(chunk, np - k0);
         hipStream_t sc = (c == 0) ? s : h->split_stream[c];
         if (c > 0) GPX_HIP(hipStreamWaitEvent(sc, h->split_ev[gpx_spgp::SPLIT], 0));
         double *Cc = (c == 0) ? C : h->split_buf + (int64_t)(c - 1) * mp * mp;
-        GPX_TRY(launch_gemm_nt(h->Wt + k0, np, h->Wt + k0, np, Cc, mp, mp, mp, kc, 1.0, (c == 0) ? beta : 0.0, 1, sc, nullptr, 1));
+        GPX_TRY(launch_gemm_nt(W + k0, np, W + k0, np, Cc, mp, mp, mp, kc, alpha, (c == 0) ? beta : 0.0, 1, sc, nullptr, 1));
         if (c > 0) {
             GPX_HIP(hipEventRecord(h->split_ev[c], sc));
             GPX_HIP(hipStreamWaitEvent(s, h->split_ev[c], 0));
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void scale_rows_inplace_kernel(double *Z, long
     for (long j = threadIdx.x; j < cols; j += 256) Z[i * ld + j] *= f;
 }
 
-enum { VEC_INV_SQRT = 0, VEC_SNELSON_EP = 1, VEC_MUL = 2, VEC_SUB = 3, VEC_SQUARE = 4 };
+enum { VEC_INV_SQRT = 0, VEC_SNELSON_EP = 1, VEC_MUL = 2, VEC_SUB = 3, VEC_SQUARE = 4, VEC_SQRT_PARTS = 5 };
 // small elementwise passes over vectors of length npad (n real entries)
 __global__ __launch_bounds__(256) void spgp_vec_kernel(int mode, long n, long npad, double vt, const double *__restrict__ p,
                                                       const double *__restrict__ q, double *__restrict__ o1, double *__restrict__ o2)
@@ -132,6 +133,10 @@ __global__ __launch_bounds__(256) void spgp_vec_kernel(int mode, long n, long np
     case VEC_MUL: o1[i] = real ? p[i] * q[i] : 0.0; break;
     case VEC_SUB: o1[i] = real ? p[i] - q[i] : 0.0; break;
     case VEC_SQUARE: o1[i] = real ? p[i] * p[i] : 0.0; break;
+    case VEC_SQRT_PARTS:    // o1 = sqrt(max(p, 0)), o2 = sqrt(max(-p, 0))
+        o1[i] = real ? sqrt(fmax(p[i], 0.0)) : 0.0;
+        o2[i] = real ? sqrt(fmax(-p[i], 0.0)) : 0.0;
+        break;
     }
 }
 
@@ -266,7 +271,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     // W^T = (Lambda^-1/2 K_NM)^T ;  B~ = K_M + 1e-5 I + W^T W                   (:856-858)
     GPX_TRY(spgp_transpose(h, h->Knm, h->ilam, h->Wt));
     GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 1e-5, 1, 2, h->LB, mp, mp, mp, s, nullptr));
-    GPX_TRY(spgp_wtw(h, h->LB, 1.0));
+    GPX_TRY(spgp_wtw(h, h->Wt, h->LB, 1.0));
     GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
     GPX_TRY(chol_factor(h->LB, mp, h->mblk, h->DinvB, h->diagB, h->info, s, nullptr, nullptr, nullptr));
     GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -369,7 +374,7 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
         GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->va, h->vb, nullptr, s));                       // vb = y / sqrt(ep)
         GPX_TRY(spgp_transpose(h, h->Z, h->va, h->Wt));                                             // Wt = V / sqrt(ep)  [M, N]
         GPX_TRY(launch_set_identity(A, mp, mp, s));
-        GPX_TRY(spgp_wtw(h, A, h->vt));                                                             // A = vt I + V V^T
+        GPX_TRY(spgp_wtw(h, h->Wt, A, h->vt));                                                             // A = vt I + V V^T
         GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
         GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));  // Lm
         GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V y
@@ -395,6 +400,246 @@ extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
     if (rc) return rc;
     // fw = sum log diag(Lm) + (N-M)/2 log vt + (y^T y - bet^T bet)/(2 vt) + sum log(ep)/2 + N/2 log 2 pi   (:1017)
     *nll_out = 0.5 * o[3] + 0.5 * (double)(n - m) * log(h->vt) + (o[0] - o[1]) / (2.0 * h->vt) + 0.5 * o[2] + 0.5 * (double)n * log(2.0 * M_PI);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Analytic gradient of Snelson's likelihood, O(N M^2) -- what an L-BFGS step of SPGPCovariance.ml_estimate needs
+// (the reference differentiates the dense N x N form instead: Covariance.py:906-979, O(N^2 M) per parameter).
+// With Q = K_M + 1e-6 I = L L^T, K = K_MN, V = L^-1 K, gamma_n = v + vt - |V_n|^2, D = diag(gamma / vt),
+// A = vt I + V D^-1 V^T, Sigma = V^T V + diag(gamma), alpha = Sigma^-1 y, G = (Sigma^-1 - alpha alpha^T) / 2, g = diag G:
+//     d nll = <Kbar, dK> + <Qbar, dQ> + sum(g) (dv + dvt)
+//     Kbar = L^-T Vbar,   Vbar = A^-1 V D^-1 - betaA alpha^T - 2 V diag(g),   betaA = A^-1 V D^-1 y
+//     Qbar = L^-T [ -(I - vt A^-1 - betaA betaA^T) / 2 + V diag(g) V^T ] L^-1
+//     alpha_n = (y_n - V_n . betaA) / gamma_n ,   g_n = ((1 - s_n) / gamma_n - alpha_n^2) / 2 ,  s_n = (A^-1 V D^-1)_n . V_n
+// (Woodbury through the M x M matrix A; derivation in oracle/oracle.py::spgp_nll_grad, which the tests pin to central
+// differences of the likelihood).  The squared-exponential kernel then needs E = Kbar o K and F = Qbar o K_M only
+// through column sums and the products E X, E X^2, F Xb: one pass over each.
+// All N x M operands are stored transposed ([N, M] row-major, like K_NM): Zt = V^T etc.
+// ------------------------------------------------------------------------------------------------------------------
+
+// one wave per row n:  T_n <- (vt / gamma_n) T_n - alpha_n betaA - 2 g_n Z_n   with  T = Zt A^-1, Z = Zt ;  gout[n] = g_n
+__global__ __launch_bounds__(256) void spgp_vbar_kernel(double *T, const double *__restrict__ Z, long ld, long mcols, long n, long npad,
+                                                       const double *__restrict__ gamma, const double *__restrict__ y,
+                                                       const double *__restrict__ betaA, double vt, double *__restrict__ gout)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= npad) return;
+    const int lane = threadIdx.x & 63;
+    double *tr = T + row * ld;
+    const double *zr = Z + row * ld;
+    if (row >= n) {
+        for (long c = 2 * lane; c < mcols; c += 128) *reinterpret_cast<v2d *>(tr + c) = (v2d){0.0, 0.0};
+        if (lane == 0) gout[row] = 0.0;
+        return;
+    }
+    double st = 0.0, sb = 0.0;
+    for (long c = 2 * lane; c < mcols; c += 128) {
+        const v2d t = *reinterpret_cast<const v2d *>(tr + c), z = *reinterpret_cast<const v2d *>(zr + c);
+        const v2d b = *reinterpret_cast<const v2d *>(betaA + c);
+        st = fma(t.y, z.y, fma(t.x, z.x, st));
+        sb = fma(z.y, b.y, fma(z.x, b.x, sb));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { st += __shfl_xor(st, o); sb += __shfl_xor(sb, o); }
+    const double gm = gamma[row], f = vt / gm;
+    const double al = (y[row] - sb) / gm;
+    const double g = 0.5 * ((1.0 - f * st) / gm - al * al);
+    for (long c = 2 * lane; c < mcols; c += 128) {
+        const v2d t = *reinterpret_cast<const v2d *>(tr + c), z = *reinterpret_cast<const v2d *>(zr + c);
+        const v2d b = *reinterpret_cast<const v2d *>(betaA + c);
+        v2d o;
+        o.x = f * t.x - al * b.x - 2.0 * g * z.x;
+        o.y = f * t.y - al * b.y - 2.0 * g * z.y;
+        *reinterpret_cast<v2d *>(tr + c) = o;
+    }
+    if (lane == 0) gout[row] = g;
+}
+
+// Qb[i][j] += -(delta_ij - vt Ainv[i][j] - b_i b_j) / 2
+__global__ __launch_bounds__(256) void spgp_qb_fix_kernel(double *Qb, const double *__restrict__ Ainv, const double *__restrict__ b, long mp, double vt)
+{
+    const long i = blockIdx.x;
+    for (long j = threadIdx.x; j < mp; j += 256)
+        Qb[i * mp + j] += -0.5 * ((i == j ? 1.0 : 0.0) - vt * Ainv[i * mp + j] - b[i] * b[j]);
+}
+
+// E = Kb o K over rows [r0, r0 + rows) x 1024 columns (blockIdx.y) x 8 coordinates (blockIdx.z):
+//   part[blockIdx.x][j][0] = sum_r E_rj ,  [1 + k] = sum_r E_rj x_rk ,  [1 + dpad + k] = sum_r E_rj x_rk^2
+constexpr int EP_RB = 1024, EP_CB = 1024, EP_DK = 8;
+__global__ __launch_bounds__(256) void spgp_epass_kernel(const double *__restrict__ Kb, const double *__restrict__ K, long ld, long nrows,
+                                                        const double *__restrict__ x, int d, int dpad, long mp, double *__restrict__ part)
+{
+    const int t = threadIdx.x;
+    const long r0 = (long)blockIdx.x * EP_RB, r1 = min(nrows, r0 + EP_RB);
+    const long cbase = (long)blockIdx.y * EP_CB;
+    const int k0 = blockIdx.z * EP_DK;
+    const int W = 1 + 2 * dpad;
+    double acc[2][2][1 + 2 * EP_DK];   // [column pair c][x / y of the pair][sums]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int w = 0; w < 1 + 2 * EP_DK; ++w) acc[c][e][w] = 0.0;
+    for (long r = r0; r < r1; ++r) {
+        double xv[EP_DK];
+#pragma unroll
+        for (int k = 0; k < EP_DK; ++k) xv[k] = (k0 + k < d) ? x[r * d + k0 + k] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const long j = cbase + 2 * t + 512 * c;
+            if (j < mp) {
+                const v2d a = *reinterpret_cast<const v2d *>(Kb + r * ld + j), b = *reinterpret_cast<const v2d *>(K + r * ld + j);
+                const double e0 = a.x * b.x, e1 = a.y * b.y;
+                acc[c][0][0] += e0;
+                acc[c][1][0] += e1;
+#pragma unroll
+                for (int k = 0; k < EP_DK; ++k) {
+                    const double p0 = e0 * xv[k], p1 = e1 * xv[k];
+                    acc[c][0][1 + k] += p0;
+                    acc[c][1][1 + k] += p1;
+                    acc[c][0][1 + EP_DK + k] = fma(p0, xv[k], acc[c][0][1 + EP_DK + k]);
+                    acc[c][1][1 + EP_DK + k] = fma(p1, xv[k], acc[c][1][1 + EP_DK + k]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const long j = cbase + 2 * t + 512 * c + e;
+            if (j < mp) {
+                double *o = part + ((long)blockIdx.x * mp + j) * W;
+                if (blockIdx.z == 0) o[0] = acc[c][e][0];
+#pragma unroll
+                for (int k = 0; k < EP_DK; ++k)
+                    if (k0 + k < dpad) { o[1 + k0 + k] = acc[c][e][1 + k]; o[1 + dpad + k0 + k] = acc[c][e][1 + EP_DK + k]; }
+            }
+        }
+}
+
+// out[i] = sum_b part[b][i]  (fixed order)
+__global__ __launch_bounds__(256) void spgp_sum_parts_kernel(const double *__restrict__ part, long elems, int nb, double *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= elems) return;
+    double s = 0.0;
+    for (int b = 0; b < nb; ++b) s += part[(long)b * elems + i];
+    out[i] = s;
+}
+
+static int spgp_epass(gpx_spgp *h, const double *Kb, const double *K, int64_t nrows, const double *x, double *part, double *out_dev)
+{
+    const int dpad = (int)round_up(h->d, EP_DK);
+    const int W = 1 + 2 * dpad;
+    const int nb = (int)((nrows + EP_RB - 1) / EP_RB);
+    dim3 grid((unsigned)nb, (unsigned)((h->mpad + EP_CB - 1) / EP_CB), (unsigned)(dpad / EP_DK));
+    hipLaunchKernelGGL(spgp_epass_kernel, grid, dim3(256), 0, h->stream, Kb, K, (long)h->mpad, (long)nrows, x, h->d, dpad, (long)h->mpad, part);
+    const long elems = (long)h->mpad * W;
+    hipLaunchKernelGGL(spgp_sum_parts_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, h->stream, (const double *)part, elems, nb, out_dev);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// grad_out [2 + d + m d]: d nll / d (log v, log vt, log w_1..d, pseudo-inputs row-major), nll = gpx_spgp_nll
+extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
+{
+    GPX_TRY(spgp_require(h));
+    if (!grad_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    const int64_t np = h->npad, mp = h->mpad, n = h->n, m = h->m;
+    const int d = h->d, dpad = (int)round_up(d, EP_DK), W = 1 + 2 * dpad;
+    const int64_t tt = h->mblk * (int64_t)TILE * TILE, mm = mp * mp;
+    const int nbE = (int)((np + EP_RB - 1) / EP_RB), nbF = (int)((mp + EP_RB - 1) / EP_RB);
+    double *mats = nullptr, *W2 = nullptr, *vecs = nullptr, *part = nullptr, *small = nullptr;
+    int info = 0;
+    std::vector<double> PE((size_t)mp * W), PF((size_t)mp * W), xbw((size_t)mp * d);
+    double sg = 0.0;
+    auto body = [&]() -> int {
+        // M x M: L, A, Ainv, Scr (L^-T), Qb, Y, Qbar, Qk ; blocks' inverses and diagonals
+        GPX_TRY(dalloc(&mats, 8 * mm + 2 * tt + 2 * mp));
+        double *L = mats, *A = L + mm, *Ainv = A + mm, *Scr = Ainv + mm, *Qb = Scr + mm, *Y = Qb + mm, *Qbar = Y + mm, *Qk = Qbar + mm;
+        double *Dinv = Qk + mm, *DinvA = Dinv + tt, *diag = DinvA + tt, *diagA = diag + mp;
+        GPX_TRY(dalloc(&W2, mp * np));
+        GPX_TRY(dalloc(&vecs, 7 * np + 3 * mp));
+        double *gam = vecs, *isq = gam + np, *yh = isq + np, *gv = yh + np, *gpos = gv + np, *gneg = gpos + np, *junk = gneg + np;
+        double *ma = junk + np, *betaA = ma + mp, *mj = betaA + mp;
+        GPX_TRY(dalloc(&part, (int64_t)std::max(nbE, nbF) * mp * W));
+        GPX_TRY(dalloc(&small, 2 * mp * W + 8));
+        double *PEd = small, *PFd = PEd + mp * W, *sgd = PFd + mp * W;
+        double *T = h->Wt;                                                                          // [np, mp] once Wt has been consumed
+
+        GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
+        if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
+        GPX_TRY(spgp_solve_into_z(h, L, Dinv));                                                     // Z = Zt = V^T
+        GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, junk, gam, s, nullptr));   // gamma = v + vt - |V_n|^2
+        GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, gam, nullptr, isq, junk, s));                  // isq = 1 / sqrt(ep), ep = gamma / vt
+        GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, isq, yh, nullptr, s));
+        GPX_TRY(spgp_transpose(h, h->Z, isq, h->Wt));                                               // Wt = V D^-1/2
+        GPX_TRY(launch_set_identity(A, mp, mp, s));
+        GPX_TRY(spgp_wtw(h, h->Wt, A, h->vt));                                                      // A = vt I + V D^-1 V^T
+        GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
+        GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));
+        GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
+        GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, yh, 0.0, ma, mj, s, nullptr));             // ma = V D^-1 y
+        GPX_HIP(hipStreamSynchronize(s));
+        if (info > 0) { gpx_set_error("vt I + V V^T is not positive definite (leading minor %d)", info); return info; }
+        GPX_TRY(build_kinv_from_factor(A, mp, h->mblk, DinvA, Scr, Ainv, s, nullptr));              // A^-1
+        GPX_TRY(launch_predict_reduce(Ainv, mp, mp, mp, ma, 0.0, betaA, mj, s, nullptr));           // betaA = A^-1 V D^-1 y
+        GPX_TRY(launch_gemm_nt(h->Z, mp, Ainv, mp, T, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));    // T = Zt A^-1
+        hipLaunchKernelGGL(spgp_vbar_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, T, (const double *)h->Z, (long)mp, (long)mp, (long)n,
+                           (long)np, (const double *)gam, (const double *)h->t, (const double *)betaA, h->vt, gv);   // T = Vbar^T
+        // Qb = V diag(g) V^T - (I - vt A^-1 - betaA betaA^T) / 2 ; g has both signs: two rank-N updates with sqrt(g+), sqrt(g-)
+        GPX_TRY(vec_op(VEC_SQRT_PARTS, n, np, 0.0, gv, nullptr, gpos, gneg, s));
+        GPX_TRY(spgp_transpose(h, h->Z, gpos, W2));
+        GPX_TRY(spgp_wtw(h, W2, Qb, 0.0, 1.0));
+        GPX_TRY(spgp_transpose(h, h->Z, gneg, W2));
+        GPX_TRY(spgp_wtw(h, W2, Qb, 1.0, -1.0));
+        GPX_TRY(launch_symmetrize_lower(Qb, mp, mp, s));
+        hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
+        // L^-T (explicit, upper triangular) -> Scr ; Y doubles as the K_M^-1 the helper also writes
+        GPX_TRY(build_kinv_from_factor(L, mp, h->mblk, Dinv, Scr, Y, s, nullptr));
+        GPX_TRY(launch_gemm_nt(T, mp, Scr, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Z = Kbar^T = Vbar^T L^-1
+        GPX_TRY(launch_gemm_nt(Scr, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));       // Y = L^-T Qb   (Qb symmetric)
+        GPX_TRY(launch_gemm_nt(Y, mp, Scr, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Qbar = L^-T Qb L^-1
+        GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 0.0, 0, 1, Qk, mp, mp, mp, s, nullptr)); // K_M (no jitter), zero padded
+        GPX_TRY(spgp_epass(h, h->Z, h->Knm, np, h->xw, part, PEd));
+        GPX_TRY(spgp_epass(h, Qbar, Qk, mp, h->xbw, part, PFd));
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, (const double *)gv, (long)np, sgd);
+        GPX_HIP(hipGetLastError());
+        GPX_HIP(hipMemcpyAsync(PE.data(), PEd, sizeof(double) * mp * W, hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipMemcpyAsync(PF.data(), PFd, sizeof(double) * mp * W, hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipMemcpyAsync(xbw.data(), h->xbw, sizeof(double) * mp * d, hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipMemcpyAsync(&sg, sgd, sizeof(double), hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
+    dfree(mats); dfree(W2); dfree(vecs); dfree(part); dfree(small);
+    if (rc) return rc;
+    // assemble (coordinates scaled by sqrt(w): (xb - x)^2 w = (xbw - xw)^2)
+    std::vector<double> g((size_t)(2 + d + m * d));
+    double sE = 0.0, sF = 0.0;
+    for (int64_t j = 0; j < m; ++j) { sE += PE[(size_t)j * W]; sF += PF[(size_t)j * W]; }
+    g[0] = sE + sF + h->v * sg;
+    g[1] = h->vt * sg;
+    std::vector<double> swh(d);
+    GPX_HIP(hipMemcpy(swh.data(), h->sw, sizeof(double) * d, hipMemcpyDeviceToHost));
+    for (int k = 0; k < d; ++k) {
+        double qe = 0.0, qf = 0.0;
+        for (int64_t j = 0; j < m; ++j) {
+            const double xb = xbw[(size_t)j * d + k];
+            qe += xb * xb * PE[(size_t)j * W] - 2.0 * xb * PE[(size_t)j * W + 1 + k] + PE[(size_t)j * W + 1 + dpad + k];
+            qf += 2.0 * xb * xb * PF[(size_t)j * W] - 2.0 * xb * PF[(size_t)j * W + 1 + k];
+            g[(size_t)(2 + d) + (size_t)j * d + k] = -swh[k] * (xb * PE[(size_t)j * W] - PE[(size_t)j * W + 1 + k])
+                                                    - 2.0 * swh[k] * (xb * PF[(size_t)j * W] - PF[(size_t)j * W + 1 + k]);
+        }
+        g[2 + k] = -0.5 * (qe + qf);
+    }
+    GPX_HIP(hipMemcpy(grad_out, g.data(), sizeof(double) * g.size(), hipMemcpyDefault));
     return 0;
 }
 

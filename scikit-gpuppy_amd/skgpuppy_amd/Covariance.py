@@ -249,6 +249,11 @@ class _SPGPDeviceModel(object):
         _gpx.check(_gpx.lib.gpx_spgp_nll(self.handle, ctypes.byref(out)), "gpx_spgp_nll")
         return out.value
 
+    def nll_grad(self):
+        out = np.empty(2 + self.d + self.m * self.d)
+        _gpx.check(_gpx.lib.gpx_spgp_nll_grad(self.handle, _gpx.ptr(out)), "gpx_spgp_nll_grad")
+        return out
+
     def dense(self, which):
         out = np.empty((self.n, self.n))
         _gpx.check(_gpx.lib.gpx_spgp_dense(self.handle, which, _gpx.ptr(out)), "gpx_spgp_dense")
@@ -308,14 +313,21 @@ class SPGPCovariance(Covariance):
         return theta
 
     def cov_matrix_ij(self, xi, xj, theta):
-        """Q_ij = K_iM (K_M + 1e-5 I)^-1 K_Mj (Covariance.py:743-763)."""
+        """Q_ij = K_iM (K_M + 1e-5 I)^-1 K_Mj (Covariance.py:743-763).  Depends on theta only through the pseudo-inputs'
+        factor: the device model behind it is fitted on the M pseudo-inputs themselves (O(M^3), not a fit of xi) and kept
+        for the next call with the same theta."""
         a = _gpx.f64(xi)
         b = _gpx.f64(xj)
-        model = self._model(a, None, theta)
-        try:
-            return model.cross(a, b)
-        finally:
-            model.close()
+        th = _gpx.f64(theta)
+        key = th.tobytes()
+        cached = getattr(self, "_cross_model", None)
+        if cached is None or cached[0] != key:
+            if cached is not None:
+                cached[1].close()
+            _tg, xb = self._split(th, a.shape[1])
+            cached = (key, self._model(xb, None, th))
+            self._cross_model = cached
+        return cached[1].cross(a, b)
 
     def cov_matrix(self, x, theta):
         """Q_N + diag(K_N - Q_N) + vt I (Covariance.py:814-833)."""
@@ -333,23 +345,31 @@ class SPGPCovariance(Covariance):
         finally:
             model.close()
 
+    def _fit_model(self, x, t, theta):
+        """the device model of (x, t, theta), kept until the next different request: L-BFGS asks for the likelihood and
+        its gradient at the same theta, one after the other"""
+        key = (id(x), id(t), _gpx.f64(theta).tobytes())
+        cached = getattr(self, "_fit_cache", None)
+        if cached is None or cached[0] != key:
+            if cached is not None:
+                cached[1].close()
+            self._fit_cache = None
+            cached = (key, self._model(x, t, theta), x, t)        # (x, t kept alive: their ids are part of the key)
+            self._fit_cache = cached
+        return cached[1]
+
     def _negativeloglikelihood(self, x, t, theta):
         """Snelson's O(N m^2) likelihood (Covariance.py:981-1019); raises LinAlgError like the reference's Cholesky."""
-        model = self._model(x, t, theta)
-        try:
-            return model.nll()
-        finally:
-            model.close()
+        return self._fit_model(x, t, theta).nll()
 
     def _d_nll_d_theta(self, x, t, theta):
-        """central differences of the GPU likelihood.  The reference's analytic gradient (Covariance.py:906-979) builds
-        2 + d + m d dense N x N derivative matrices and is itself only checked against central differences
-        (skgpuppy/tests/tests.py:538-565)."""
-        theta = np.asarray(theta, dtype=float)
-        g = np.empty(len(theta))
-        delta = 1e-5
-        for j in range(len(theta)):
-            e = np.zeros(len(theta))
-            e[j] = delta
-            g[j] = (self._negativeloglikelihood(x, t, theta + e) - self._negativeloglikelihood(x, t, theta - e)) / (2 * delta)
-        return g
+        """analytic gradient of Snelson's likelihood in O(N m^2) on the GPU (gpx_spgp_nll_grad).  The reference's own
+        (Covariance.py:906-979) differentiates the dense N x N likelihood at O(N^2 m) per parameter and is itself only
+        checked against central differences (skgpuppy/tests/tests.py:538-565)."""
+        return self._fit_model(x, t, theta).nll_grad()
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_cross_model", None)          # device handles never enter a pickle
+        state.pop("_fit_cache", None)
+        return state

@@ -64,6 +64,7 @@ SIGNATURES = {
     "gpx_spgp_free": (None, [_hp]),
     "gpx_spgp_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
     "gpx_spgp_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
+    "gpx_spgp_nll_grad": (_int, [_hp, _dp]),
     "gpx_spgp_dense": (_int, [_hp, _int, _dp]),
     "gpx_spgp_cross": (_int, [_hp, _dp, _i64, _dp, _i64, _dp]),
     "gpx_profile_enable": (_int, [_hp, _int]),

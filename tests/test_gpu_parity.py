@@ -671,15 +671,35 @@ def test_spgp_gradient_and_bad_arguments():
     tc = t - t.mean()
     gr = cov._d_nll_d_theta(x, tc, th)
     assert gr.shape == th.shape and np.all(np.isfinite(gr))
-    # directional derivative agrees with a coarser difference quotient of the oracle
+    # the analytic O(N m^2) gradient (gpx_spgp_nll_grad) against the oracle's (pinned to central differences of the
+    # likelihood in tests/test_oracle_golden.py; the reference's own gradient does not run on Python 3: parity unpinned)
+    og = orc.spgp_nll_grad(x, tc, th, m)
+    np.testing.assert_allclose(gr, og, rtol=0, atol=1e-7 * np.abs(og).max())
     e = np.zeros(len(th)); e[0] = 1e-4
     fd = (orc.spgp_nll(x, tc, th + e, m) - orc.spgp_nll(x, tc, th - e, m)) / 2e-4
-    assert gr[0] == pytest.approx(fd, rel=1e-3, abs=1e-3)
+    assert gr[0] == pytest.approx(fd, rel=1e-5, abs=1e-5)
     with pytest.raises(ValueError):
         cov.cov_matrix(x, th[:-1])
     start = cov.get_theta(x, tc)
     assert start.shape == th.shape
     assert np.isfinite(cov._negativeloglikelihood(x, tc, start))
+
+
+@pytest.mark.parametrize("N,d,m", [(300, 2, 7), (1500, 3, 130), (5000, 10, 257), (20000, 4, 300)])
+def test_spgp_analytic_gradient_against_oracle(N, d, m):
+    """gpx_spgp_nll_grad on ragged shapes: m below / across / above a 128-tile, d above one 8-coordinate chunk of the
+    E-pass, N across the split-K threshold of the rank-N products."""
+    rng = np.random.RandomState(N + m)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    t = t - t.mean()
+    xb = x[rng.choice(N, m, replace=False)] + 0.05 * rng.randn(m, d)
+    th = np.concatenate([np.log([1.7, 0.02]), np.log(rng.uniform(0.02, 0.08, d)), xb.ravel()])
+    cov = sk.SPGPCovariance(m)
+    gr = cov._d_nll_d_theta(x, t, th)
+    assert cov._negativeloglikelihood(x, t, th) == pytest.approx(orc.spgp_nll(x, t, th, m), rel=1e-9)
+    og = orc.spgp_nll_grad(x, t, th, m)
+    np.testing.assert_allclose(gr, og, rtol=0, atol=2e-7 * np.abs(og).max())
 
 
 def test_spgp_full_size_properties():

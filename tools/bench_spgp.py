@@ -36,7 +36,7 @@ def main():
     xb = x[rng.choice(a.n, a.m, replace=False)].copy()
     theta = np.concatenate([th_gc, xb.ravel()])
     cov = sk.SPGPCovariance(a.m)
-    fit, pred, nll = [], [], []
+    fit, pred, nll, grad, lbfgs = [], [], [], [], []
     for r in range(a.reps + 1):
         t0 = time.perf_counter()
         gp = sk.GaussianProcess(x, t, cov, theta)
@@ -45,13 +45,23 @@ def main():
         t2 = time.perf_counter()
         val = gp._dev().nll()
         t3 = time.perf_counter()
-        if r:   # first round = warm-up (allocator, code objects)
-            fit.append(t1 - t0); pred.append(t2 - t1); nll.append(t3 - t2)
+        g = gp._dev().nll_grad()
+        t4 = time.perf_counter()
         gp._dev().close()
+        # one L-BFGS iteration as SPGPCovariance.ml_estimate drives it: likelihood + gradient at a new theta (host arrays in)
+        th2 = theta + 1e-3 * (r + 1)
+        t5 = time.perf_counter()
+        f2 = cov._negativeloglikelihood(x, t - t.mean(), th2)
+        g2 = cov._d_nll_d_theta(x, t - t.mean(), th2)
+        t6 = time.perf_counter()
+        if r:   # first round = warm-up (allocator, code objects)
+            fit.append(t1 - t0); pred.append(t2 - t1); nll.append(t3 - t2); grad.append(t4 - t3); lbfgs.append(t6 - t5)
     N, M = a.n, a.m
     flops_fit = N * M * M + N * M * M + M ** 3 / 3 * 2     # TRSM + lower-only W^T W + two Cholesky
     out = {"workload": "SPGP fit + estimate_many, N=%d M=%d d=%d, %d queries" % (N, M, a.d, a.queries),
            "fit_ms": 1e3 * min(fit), "predict_ms": 1e3 * min(pred), "snelson_nll_ms": 1e3 * min(nll),
+           "analytic_gradient_ms": 1e3 * min(grad), "ml_fit_iteration_ms": 1e3 * min(lbfgs),
+           "gradient_entries": int(g.size), "gradient_finite": bool(np.all(np.isfinite(g)) and np.all(np.isfinite(g2)) and np.isfinite(f2)),
            "fit_tflops_algorithmic": flops_fit / min(fit) / 1e12,
            "train_pts_per_s": N / min(fit), "query_pts_per_s": a.queries / min(pred),
            "nll": val, "mean_abs_residual": float(np.abs(mu - np.sin(0.3 * xs.sum(1))).mean()), "var_range": [float(var.min()), float(var.max())]}
