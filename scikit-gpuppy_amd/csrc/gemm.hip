@@ -248,7 +248,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
         const int lid = ktrim ? orig : xcd_chunk_start(nwg, orig & 7) + (orig >> 3);
         if (LOWER) lower_tile(lid, tri_off, tri_rows, by, bx);
-        else if (!ba.nq && ba.tri == GEMM_TRI_B_LOWER) {
+        else if (!ba.nq && ba.tri == GEMM_TRI_B_LOWER_PAIRED) {
+            // column tiles bx and (ncols - 1 - bx) of one row tile go to the same workgroup (tri_off = ncols): every
+            // workgroup contracts over (ncols + 1) * BTN -- equal work, and half as many workgroups to place
+            bx = blockIdx.x;
+            by = blockIdx.y;
+        } else if (!ba.nq && ba.tri == GEMM_TRI_B_LOWER) {
             // column tile bx contracts over (bx + 1) * BTN only: longest tiles first, in dispatch order, so that the short
             // ones fill the tail of the launch
             bx = gx - 1 - orig / gy;
@@ -276,18 +281,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     // Rectangular launches: A alone is upper triangular with its diagonal shifted by ktrim - 1 columns to the left of its
     // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
     // k = max(0, by * BTM - (ktrim - 1)).
-    long kstart = 0;
-    int kend = K;
-    if (ktrim) {
-        kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
-        if (kstart < 0) kstart = 0;
-        if (kstart > K) kstart = K;
+    const int nrep = (!ba.nq && ba.tri == GEMM_TRI_B_LOWER_PAIRED) ? 2 : 1;
+    for (int rep = 0; rep < nrep; ++rep) {
+        if (rep) bx = tri_off - 1 - bx;   // (nothing reads the staging buffers after a tile's last barrier: the next tile may start at once)
+        long kstart = 0;
+        int kend = K;
+        if (ktrim) {
+            kstart = LOWER ? (long)by * BTM : (long)by * BTM - (long)(ktrim - 1);
+            if (kstart < 0) kstart = 0;
+            if (kstart > K) kstart = K;
+        }
+        // one triangular operand (square problems), GemmBatch::tri of the A descriptor
+        if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
+        else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
+        else if (ba.tri == GEMM_TRI_B_LOWER || ba.tri == GEMM_TRI_B_LOWER_PAIRED) kend = min(K, (bx + 1) * BTN);   // B[j][k] = 0 for k > j
+        gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
     }
-    // batched launches (square problems, M = N = K): one triangular operand, GemmBatch::tri of the A descriptor
-    if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
-    else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
-    else if (ba.tri == GEMM_TRI_B_LOWER) kend = min(K, (bx + 1) * BTN);            // B[j][k] = 0 for k > j
-    gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
 }
 
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
@@ -349,7 +358,12 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
                                (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, na_, nb_, nb_);                                  \
     } while (0)
-    if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
+    if (tri == GEMM_TRI_B_LOWER && tiles >= SMALL_GRID_TILES && (N / TILE) % 2 == 0) {
+        // column tiles of length (bx + 1) * 128: pair bx with its mirror image so that every workgroup does the same work
+        const GemmBatch pa_ = {0, 0, 0, GEMM_TRI_B_LOWER_PAIRED};
+        hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
+                           (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
+    } else if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);
