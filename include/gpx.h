@@ -123,6 +123,9 @@ int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out /* [d] */)
  * (skgpuppy/UncertaintyPropagation.py:246-379, UncertaintyPropagation2.pyx:57-184) ----
  * mean WITHOUT meant; var = (v+vt) - sum_ij (Kinv_ij - beta_i beta_j) L_ij - mean^2. */
 int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var);
+/* row-sharded form (multi-GPU host): partial_out[3] = { sum_{i in rows} beta_i l_i, the rows' share of the double sum / nc2,
+ * nc2 }; summed over the row panels: mean = p0, var = v + vt - nc2 p1 - p0^2.  Same row alignment as gpx_propagate_approx_rows. */
+int gpx_propagate_exact_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1, double *partial_out);
 int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean);
 
 /* ---- "next" row f1: hyper-parameter likelihood at the handle's theta

@@ -22,7 +22,7 @@ int launch_kinv_pass(const double *Kinv, int64_t ld, int64_t npad, int nc, const
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev, hipStream_t s);
 int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
                      const double *bT, const double *e, const double *F, double *partial, double *out_dev, hipStream_t s,
-                     Profiler *prof);
+                     Profiler *prof, int64_t row0 = 0, int64_t row1 = 0);
 int launch_approx_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev, double v,
                         double vt, double *VM, double *AUX, double *cplain, hipStream_t s);
 int launch_trace(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
@@ -942,7 +942,10 @@ static int small_inverse(const double *A, int d, double *inv)
     return 0;
 }
 
-static int exact_common(gpx_handle *h, const double *u, const double *Sigma, bool want_var, double *mean, double *var)
+// row0 / row1 (row1 > 0): only the rows [row0, row1) of the sums; then *mean / *var receive the PARTIAL sums  sum_i beta_i l_i
+// and  sum_{i in rows, j <= i} w_ij (Kinv_ij - beta_i beta_j) L_ij / nc2,  and *nc2_out the normaliser
+static int exact_common(gpx_handle *h, const double *u, const double *Sigma, bool want_var, double *mean, double *var,
+                        int64_t row0 = 0, int64_t row1 = 0, double *nc2_out = nullptr)
 {
     const int d = h->d;
     const int64_t np = h->npad;
@@ -984,10 +987,13 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     if (er == hipSuccess) er = hipMemcpyAsync(ud, uh, sizeof(double) * d, hipMemcpyHostToDevice, s);
     if (er != hipSuccess) { dfree(buf); gpx_set_error("exact: constant upload failed"); return GPX_ERR_HIP; }
     rc = launch_exact_build(h->x, h->n, np, d, ud, h->wdev, Lsd, ddd, h->v, h->vt, nc1, aT, bT, e, F, lm, s);
+    const bool ranged = row1 > 0;
+    const int64_t r0 = ranged ? row0 : 0, r1 = ranged ? round_up(row1, TILE) : np;   // rows past n are padding (l, F are zero there)
     std::vector<std::pair<const double *, const double *>> pr;
-    pr.push_back({h->alpha, lm});
-    if (!rc) rc = launch_dot_pairs(pr, np, outd, s);
-    if (!rc && want_var) rc = launch_exact_sum(h->Kinv, np, np, d, h->alpha, aT, bT, e, F, partial, outd + 1, s, &h->prof);
+    pr.push_back({h->alpha + r0, lm + r0});
+    if (!rc && r1 > r0) rc = launch_dot_pairs(pr, r1 - r0, outd, s);
+    else if (!rc) er = hipMemsetAsync(outd, 0, sizeof(double) * 2, s);
+    if (!rc && want_var) rc = launch_exact_sum(h->Kinv, np, np, d, h->alpha, aT, bT, e, F, partial, outd + 1, s, &h->prof, r0, ranged ? r1 : 0);
     double o[2] = {0, 0};
     if (!rc) {
         er = hipMemcpyAsync(o, outd, sizeof(double) * 2, hipMemcpyDeviceToHost, s);
@@ -997,8 +1003,34 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     dfree(buf);
     if (rc) return rc;
     const double mu = o[0];
+    if (nc2_out) *nc2_out = nc2;
+    if (ranged) {   // partial sums: the caller adds them over the row panels and finishes
+        if (mean) *mean = o[0];
+        if (var) *var = o[1];
+        return 0;
+    }
     if (mean) *mean = mu;
     if (want_var && var) *var = (h->v + h->vt) - nc2 * o[1] - mu * mu;   // UncertaintyPropagation.py:377
+    return 0;
+}
+
+// Row-sharded Exact propagation for the multi-GPU host: partial_out = [ sum_{i in rows} beta_i l_i ,
+// sum_{i in rows, j <= i} w_ij (Kinv_ij - beta_i beta_j) L_ij / nc2 , nc2 ].  After adding the first two over the row panels:
+// mean = p0 (+ meant), var = v + vt - nc2 p1 - p0^2  (UncertaintyPropagation.py:377).  The j <= i triangle makes row i cost
+// i + 1 pairs: shard by equal AREA (skgpuppy_amd.distributed.row_shards(..., triangular=True)).
+extern "C" int gpx_propagate_exact_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1,
+                                        double *partial_out)
+{
+    CHECK_H(h);
+    if (!u || !Sigma || !partial_out || row0 < 0 || row1 < row0 || row1 > h->n || (row0 % TILE && row0 != h->n) || (row1 % TILE && row1 != h->n)) {
+        gpx_set_error("gpx_propagate_exact_rows: bad arguments (rows [%ld, %ld) of %ld)", (long)row0, (long)row1, (long)h->n);
+        return GPX_ERR_BAD_ARG;
+    }
+    double p[3] = {0.0, 0.0, 0.0};
+    if (row1 > row0) GPX_TRY(exact_common(h, u, Sigma, true, &p[0], &p[1], row0, row1, &p[2]));
+    else GPX_TRY(exact_common(h, u, Sigma, false, nullptr, nullptr, 0, 0, &p[2]));   // empty panel: the normaliser only
+    if (row1 <= row0) { p[0] = 0.0; p[1] = 0.0; }
+    GPX_HIP(hipMemcpy(partial_out, p, sizeof(double) * 3, hipMemcpyDefault));
     return 0;
 }
 

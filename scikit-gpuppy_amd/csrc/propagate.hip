@@ -256,13 +256,13 @@ template <int DMAX>
 __global__ __launch_bounds__(256, 2) void exact_sum_kernel(const double *__restrict__ Kinv, long ld, long npad, int d,
                                                        const double *__restrict__ beta, const double *__restrict__ aT,
                                                        const double *__restrict__ bT, const double *__restrict__ e,
-                                                       const double *__restrict__ F, double *__restrict__ partial)
+                                                       const double *__restrict__ F, double *__restrict__ partial, int rb_base)
 {
     __shared__ __attribute__((aligned(16))) double bs[EXR][DMAX];   // b_i for the block's 16 rows (broadcast reads), zero padded
     __shared__ double rs[EXR][3];                                   // e_i, F_i, beta_i
     __shared__ double ws[4];
     const int t = threadIdx.x;
-    const int rb = gridDim.x - 1 - blockIdx.x;
+    const int rb = rb_base + gridDim.x - 1 - blockIdx.x;           // the launch covers row blocks [rb_base, rb_base + gridDim.x)
     const long i0 = (long)rb * EXR;
     for (int q = t; q < EXR * DMAX; q += 256) {
         const int r = q / DMAX, k = q - r * DMAX;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void exact_sum_kernel(const double *__restr
     s = wave_sum_p(s);
     if ((t & 63) == 0) ws[t >> 6] = s;
     __syncthreads();
-    if (t == 0) partial[rb] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (t == 0) partial[rb - rb_base] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -417,26 +417,29 @@ __global__ __launch_bounds__(256) void sum_vector_kernel(const double *__restric
     if (threadIdx.x == 0) *out = (ws[0] + ws[1]) + (ws[2] + ws[3]);
 }
 
+// rows [row0, row1) of the j <= i half (multiples of EXR; row1 <= 0: all rows)
 int launch_exact_sum(const double *Kinv, int64_t ld, int64_t npad, int d, const double *beta, const double *aT,
                      const double *bT, const double *e, const double *F, double *partial, double *out_dev,
-                     hipStream_t s, Profiler *prof)
+                     hipStream_t s, Profiler *prof, int64_t row0, int64_t row1)
 {
-    const unsigned nblk = (unsigned)(npad / EXR);
+    if (row1 <= 0) { row0 = 0; row1 = npad; }
+    const int rb0 = (int)(row0 / EXR);
+    const unsigned nblk = (unsigned)((row1 - row0) / EXR);
+    if (nblk == 0) {
+        GPX_HIP(hipMemsetAsync(out_dev, 0, sizeof(double), s));
+        return 0;
+    }
     {
-        // algorithmic flops: N^2 (2d + ~25) + N^2 exp
-        ProfScope ps(prof, s, GPX_K_EXACT, 0.5 * (double)npad * (double)npad * (2.0 * d + 25.0));   // j <= i pairs only
-        if (d <= 2)
-            hipLaunchKernelGGL(exact_sum_kernel<2>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
-        else if (d <= 4)
-            hipLaunchKernelGGL(exact_sum_kernel<4>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
-        else if (d <= 8)
-            hipLaunchKernelGGL(exact_sum_kernel<8>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
-        else if (d <= 16)
-            hipLaunchKernelGGL(exact_sum_kernel<16>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
-        else if (d <= 32)
-            hipLaunchKernelGGL(exact_sum_kernel<32>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
-        else
-            hipLaunchKernelGGL(exact_sum_kernel<64>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial);
+        // algorithmic flops: N^2 (2d + ~25) + N^2 exp, j <= i pairs only
+        ProfScope ps(prof, s, GPX_K_EXACT, 0.5 * ((double)row1 * (double)row1 - (double)row0 * (double)row0) * (2.0 * d + 25.0));
+#define GPX_EXACT(DM) hipLaunchKernelGGL(exact_sum_kernel<DM>, dim3(nblk), dim3(256), 0, s, Kinv, (long)ld, (long)npad, d, beta, aT, bT, e, F, partial, rb0)
+        if (d <= 2) GPX_EXACT(2);
+        else if (d <= 4) GPX_EXACT(4);
+        else if (d <= 8) GPX_EXACT(8);
+        else if (d <= 16) GPX_EXACT(16);
+        else if (d <= 32) GPX_EXACT(32);
+        else GPX_EXACT(64);
+#undef GPX_EXACT
     }
     hipLaunchKernelGGL(sum_vector_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, (long)nblk, out_dev);
     GPX_HIP(hipGetLastError());

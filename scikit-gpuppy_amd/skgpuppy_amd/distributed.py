@@ -384,11 +384,17 @@ def combine_approx_partials(o, Sigma, v, vt):
     return mu, s2 + var2 + var3, s2, var2 + var3
 
 
-def row_shards(n, world):
-    """[lo, hi) per rank: 128-aligned row panels of (almost) equal height"""
+def row_shards(n, world, triangular=False):
+    """[lo, hi) per rank: 128-aligned row panels of (almost) equal height -- or, with `triangular`, of (almost) equal AREA
+    of the lower triangle (row i of the Exact propagation's j <= i double sum costs i + 1 pairs)."""
     nblk = (n + TILE - 1) // TILE
-    per = (nblk + world - 1) // world
-    return [(min(n, r * per * TILE), min(n, (r + 1) * per * TILE)) for r in range(world)]
+    if triangular:
+        cuts = [int(round(nblk * np.sqrt(r / float(world)))) for r in range(world + 1)]
+    else:
+        per = (nblk + world - 1) // world
+        cuts = [min(nblk, r * per) for r in range(world + 1)]
+    cuts[0], cuts[-1] = 0, nblk
+    return [(min(n, cuts[r] * TILE), min(n, max(cuts[r], cuts[r + 1]) * TILE)) for r in range(world)]
 
 
 class ShardedGaussianProcess(object):
@@ -532,6 +538,28 @@ class ShardedGaussianProcess(object):
         mu, var, _s2, _rest = combine_approx_partials(tot.cpu().numpy(), S, float(np.exp(self.theta_min[0])),
                                                       float(np.exp(self.theta_min[1])))
         return mu + self.meant, var
+
+    def propagate_exact_sharded(self, u, Sigma):
+        """UncertaintyPropagationExact.propagate_GA (skgpuppy/UncertaintyPropagation.py:246-379) shared by all ranks
+        (collective): the j <= i double sum over (Kinv_ij - beta_i beta_j) L_ij is cut into row panels of equal area, each rank
+        sums its panel (gpx_propagate_exact_rows) and two partial sums meet in one all-reduce."""
+        import torch
+        import torch.distributed as dist
+        from . import _gpx
+        u = _gpx.f64(u)
+        S = _gpx.f64(Sigma)
+        lo, hi = row_shards(self.n, self.world, triangular=True)[self.rank]
+        part = np.zeros(3)
+        _gpx.check(_gpx.lib.gpx_propagate_exact_rows(self._h, _gpx.ptr(u), _gpx.ptr(S), lo, hi, _gpx.ptr(part)),
+                   "gpx_propagate_exact_rows")
+        tot = torch.as_tensor(part[:2].copy())
+        if self._on_device:
+            tot = tot.to(self.device)
+        if self.world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        p0, p1 = [float(v_) for v_ in tot.cpu()]
+        v, vt = float(np.exp(self.theta_min[0])), float(np.exp(self.theta_min[1]))
+        return p0 + self.meant, (v + vt) - part[2] * p1 - p0 * p0
 
     def propagate_many(self, us, Sigmas):
         """many independent propagations (the inverse-propagation and design-study workload): the CALLS are sharded

@@ -58,8 +58,14 @@ def main():
             owant = orc.approx_propagate(og_, us[i], Ss[i])
             ok = ok and abs(sm - pm[i]) < 1e-9 and abs(sv - pv[i]) < 1e-9
             ok = ok and abs(sm - owant[0]) < 1e-8 and abs(sv - owant[1]) < 2e-8
+        em, ev = gp.propagate_exact_sharded(us[i], Ss[i])
+        if rank == 0:
+            ewant = sk.UncertaintyPropagationExact(ref).propagate_GA(us[i], Ss[i])
+            eo = orc.exact_propagate(og_, us[i], Ss[i])
+            ok = ok and abs(em - ewant[0]) < 1e-9 and abs(ev - ewant[1]) < 1e-9
+            ok = ok and abs(em - eo[0]) < 1e-8 and abs(ev - eo[1]) < 2e-8
     if rank == 0:
-        print("row-sharded propagate_GA vs call-sharded and oracle:", ok)
+        print("row-sharded propagate_GA / Exact vs call-sharded, single-GPU and oracle:", ok)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     gp.close()

@@ -41,6 +41,13 @@ def test_row_shards_and_partial_combination():
         sh = row_shards(n, world)
         assert sh[0][0] == 0 and sh[-1][1] == n and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
         assert all((lo % 128 == 0 or lo == n) and (hi % 128 == 0 or hi == n) for lo, hi in sh)
+    for n, world in ((1000, 3), (16384, 8), (65536, 8), (130, 4)):
+        sh = row_shards(n, world, triangular=True)
+        assert sh[0][0] == 0 and sh[-1][1] == n and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+        assert all((lo % 128 == 0 or lo == n) and (hi % 128 == 0 or hi == n) and hi >= lo for lo, hi in sh)
+        if n >= 16384:      # equal area of the lower triangle within a few per cent
+            area = [hi * hi - lo * lo for lo, hi in sh]
+            assert max(area) < 1.15 * min(area)
     rng = np.random.RandomState(5)
     n, d = 300, 3
     x = rng.uniform(0, 10, (n, d))

@@ -490,6 +490,9 @@ for i in range(2):
     want = up.propagate_GA(us[i], Ss[i])
     got = gp.propagate_GA_sharded(us[i], Ss[i])
     assert abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9 and abs(got[0] - want[0]) < 1e-9 and abs(got[1] - want[1]) < 1e-9
+    ew = sk.UncertaintyPropagationExact(ref).propagate_GA(us[i], Ss[i])
+    eg = gp.propagate_exact_sharded(us[i], Ss[i])
+    assert abs(eg[0] - ew[0]) < 1e-9 and abs(eg[1] - ew[1]) < 1e-9
 gp.close()
 # a tight cluster with vt = 0: K is numerically indefinite -> the single-GPU fit takes the +1e-5 jitter, and so must the sharded one
 xd = rng.uniform(0, 1e-4, (600, d)); td = rng.randn(600); xs = rng.uniform(0, 1e-4, (77, d))
