@@ -380,9 +380,21 @@ extern "C" void gpx_free(gpx_handle *h)
 static int factor_once(gpx_handle *h, double add_diag, int *info_host)
 {
     hipStream_t s = h->stream;
-    GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
-    GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top));
+    const int64_t c1 = CHOL_PANEL_COLS;
+    if (h->npad <= c1 || !h->s_pan) {
+        GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
+        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top));
+    } else {
+        // the first panel's columns now; the rest of the (lower) Gram matrix underneath the first panel's diagonal chain
+        GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, std::min<int64_t>(h->n, c1), h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, c1, s, &h->prof));
+        const std::function<int()> rest = [&]() -> int {
+            const double *xr = h->xs_w + c1 * h->d;
+            return launch_gram(xr, h->n - c1, xr, h->n - c1, h->d, h->v, add_diag, 1, 2, h->L + c1 * h->npad + c1, h->npad, h->npad - c1,
+                               h->npad - c1, s, &h->prof);
+        };
+        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, &rest));
+    }
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;

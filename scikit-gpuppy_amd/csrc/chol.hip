@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <mutex>
 
 #include "common.h"
@@ -419,6 +420,7 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
 // updates): see skgpuppy_amd/distributed.py.
 // ------------------------------------------------------------------------------------------------
 constexpr int64_t CHOL_NBP = 8;
+static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 
 // factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
 // steps j in [j0,j1) of the diagonal square [B0,B1): leaf (factor + inverse), in-place TRSM leaf of the rows below
@@ -529,11 +531,13 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, Profiler *prof, hipStream_t s_top)
+                hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork)
 {
-    if (nblk <= CHOL_NBP || s_pan == nullptr)
+    if (nblk <= CHOL_NBP || s_pan == nullptr) {
+        if (after_fork) GPX_TRY((*after_fork)());
         return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                   : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
+    }
     // outer panel boundaries (block units).  Wider early panels (12..32 blocks) were measured and are slower.
     std::vector<int64_t> Bs{0};
     while (Bs.back() < nblk) Bs.push_back(std::min<int64_t>(nblk, Bs.back() + CHOL_NBP));
@@ -569,6 +573,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             tops[q].events = &top_events;
         }
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
+        // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued now, it runs
+        // underneath the first panel's chain
+        if (after_fork) GPX_TRY((*after_fork)());
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0]));
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -160,8 +161,12 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
                       hipStream_t s, Profiler *prof);
 
 // recursive blocked algorithms (chol.hip)
+// after_fork: main-stream work that only the panels after the first depend on (called once, right after the first panel's
+// chain has been forked off; with the single-stream schedules: before anything else)
+constexpr int64_t CHOL_PANEL_COLS = 8 * 128;   // outer panel width (CHOL_NBP tiles)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
-                hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr);
+                hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr,
+                const std::function<int()> *after_fork = nullptr);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,

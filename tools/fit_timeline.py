@@ -32,6 +32,10 @@ def main():
     seeds = [i for i, r in enumerate(rows) if "ts_seed" in r[0]]
     i1 = seeds[k]
     i0 = max(i for i in range(i1) if "gram_kernel" in rows[i][0])
+    # the fit assembles the first panel's columns in a launch of its own just before the rest of the Gram matrix
+    for i in range(i0 - 1, max(i0 - 6, -1), -1):
+        if "gram_kernel" in rows[i][0] and rows[i0][1] - rows[i][2] < 200000:
+            i0 = i
     t0 = rows[i0][1]
     win = rows[i0:i1]
     print("fit window %.2f ms" % ((rows[i1][1] - t0) / 1e6))
