@@ -187,6 +187,11 @@ int gpx_bench_fp64_pipes(int blocks, int iters, int mode, double *tflops, double
 int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_dev, int64_t n2, int d, const double *theta,
                  double add_diag, int lower_only, int pad_identity,
                  double *out_dev, int64_t ld, int64_t rows_pad, int64_t cols_pad, void *stream);
+/* the same for inputs already multiplied by sqrt(w) column-wise and resident on the device: one asynchronous launch, no
+ * allocation, no synchronisation (v = exp(theta[0])) */
+int gpx_dev_gram_scaled(const double *xiw_dev, int64_t n1, const double *xjw_dev, int64_t n2, int d, double v, double add_diag,
+                        int lower_only, int pad_identity, double *out_dev, int64_t ld, int64_t rows_pad, int64_t cols_pad,
+                        void *stream);
 /* C = alpha * A B^T + beta * C  with A[M,K], B[N,K]; lower_only skips tiles above the diagonal */
 int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream);
@@ -202,6 +207,12 @@ int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, in
  * the per-panel step the multi-GPU host (skgpuppy_amd/distributed.py) runs on the panel owner. */
 int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *dinv, double *diag,
                        int *info_dev, void *stream);
+/* the same, preceded by the rank-kp update with the PREVIOUS panel that the block columns [B0,B1) still lack:
+ * prev = its rows from B0 * GPX_TILE down ([rows, kp], leading dimension ldp; it may live in L or in a receive buffer).  The
+ * diagonal square is updated first so that the chain starts at once; the rows below are updated on the side stream ahead
+ * of the column solves (the look-ahead order of the single-GPU factorisation). */
+int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, const double *prev, int64_t ldp,
+                            int64_t kp, double *dinv, double *diag, int *info_dev, void *stream);
 /* build a handle around an EXISTING factor in HBM (L [npad,npad] with ld == npad, dinv [npad/128,128,128],
  * diag [npad]; the caller keeps ownership and must keep them alive): solves for alpha; predict / propagate as usual.
  * The strictly-upper 128x128 tiles of L_dev are scratch for the library (the first Approx propagation stores L^T there).

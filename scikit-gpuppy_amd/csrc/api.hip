@@ -314,6 +314,18 @@ extern "C" int gpx_dev_gram(const double *xi_dev, int64_t n1, const double *xj_d
     return 0;
 }
 
+// the same on inputs the caller has already scaled by sqrt(w) (and keeps resident): one asynchronous launch, no allocation,
+// no synchronisation -- what the multi-GPU host calls once per owned panel
+extern "C" int gpx_dev_gram_scaled(const double *xiw_dev, int64_t n1, const double *xjw_dev, int64_t n2, int d, double v, double add_diag,
+                                   int lower_only, int pad_identity, double *out_dev, int64_t ld, int64_t rows_pad, int64_t cols_pad,
+                                   void *stream)
+{
+    GPX_TRY(gpx_require_device());
+    if (n1 < 0 || n2 < 0 || !out_dev || !xiw_dev || !xjw_dev || !(v > 0.0)) { gpx_set_error("gpx_dev_gram_scaled: bad arguments"); return GPX_ERR_BAD_ARG; }
+    return launch_gram(xiw_dev, n1, xjw_dev, n2, d, v, add_diag, lower_only, pad_identity ? 2 : 1, out_dev, ld, rows_pad, cols_pad,
+                       (hipStream_t)stream, nullptr);
+}
+
 extern "C" int gpx_gram(const double *xi, int64_t n1, const double *xj, int64_t n2, int d, const double *theta,
                         double add_diag, double *K_out)
 {
@@ -356,6 +368,18 @@ extern "C" int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B
         return GPX_ERR_BAD_ARG;
     }
     return chol_panel_factor_piped(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, const double *prev, int64_t ldp,
+                                       int64_t kp, double *dinv, double *diag, int *info_dev, void *stream)
+{
+    GPX_TRY(gpx_require_device());
+    if (!L || !prev || !dinv || !diag || !info_dev || B0 < 0 || B1 <= B0 || B1 > nblk || ld < nblk * TILE || ldp < kp || kp <= 0 || kp % 16 ||
+        (ldp & 1) || ((uintptr_t)prev & 15)) {
+        gpx_set_error("gpx_dev_chol_panel_next: bad arguments");
+        return GPX_ERR_BAD_ARG;
+    }
+    return chol_panel_factor_piped(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr, prev, ldp, kp);
 }
 
 // ---- fit ---------------------------------------------------------------------------------------

@@ -499,11 +499,20 @@ static void retire_events(const std::vector<hipEvent_t> &fresh)
 // The same with the rows below the square solved column by column on a side stream alongside the chain (TopPipe, as in
 // chol_factor): the multi-GPU host's panel owner runs this.  Fork / join inside: on return everything is ordered behind `s`.
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
-                            int *info_dev, hipStream_t s, Profiler *prof)
+                            int *info_dev, hipStream_t s, Profiler *prof, const double *P, int64_t ldp, int64_t kp)
 {
+    // P (optional): rows >= B0 * 128 of the PREVIOUS panel (kp columns, leading dimension ldp) whose rank-kp update this
+    // panel still lacks.  The diagonal square gets it first, on `s`, so that the chain starts at once; the rows below
+    // get it on the side stream, ahead of the column solves that need them (the single-GPU schedule's order).
+    const int64_t c0 = B0 * TILE, w = (B1 - B0) * TILE, below = (nblk_all - B1) * TILE;
+    double *Csq = L + c0 * ld + c0;
+    if (P) GPX_TRY(launch_gemm_nt(P, ldp, P, ldp, Csq, ld, w, w, kp, -1.0, 1.0, 0, s, prof));
     if (nblk_all <= B1) return chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof);
     hipStream_t st = stream_acquire(1);
-    if (!st) return chol_panel_factor(L, ld, nblk_all, B0, B1, Dinv, diagL, info_dev, s, prof);
+    if (!st) {
+        if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, s, prof));
+        return chol_panel_factor(L, ld, nblk_all, B0, B1, Dinv, diagL, info_dev, s, prof);
+    }
     std::vector<hipEvent_t> events;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto run = [&]() -> int {
@@ -511,6 +520,7 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
         GPX_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
         GPX_HIP(hipEventRecord(e0, s));
         GPX_HIP(hipStreamWaitEvent(st, e0, 0));
+        if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, st, prof));
         TopPipe top;
         top.stream = st; top.r0 = B1; top.r1 = nblk_all; top.events = &events;
         GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof, &top));

@@ -75,9 +75,11 @@ SIGNATURES = {
     "gpx_bench_hbm": (_int, [_i64, _int, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_bench_fp64_pipes": (_int, [_int, _int, _int] + [ctypes.POINTER(_dbl)] * 3),
     "gpx_dev_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
+    "gpx_dev_gram_scaled": (_int, [_dp, _i64, _dp, _i64, _int, _dbl, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
     "gpx_dev_gemm_nt": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, _int, ctypes.c_void_p]),
     "gpx_dev_potrf_leaf": (_int, [_dp, _i64, _dp, _dp, ctypes.c_void_p, _int, ctypes.c_void_p]),
     "gpx_dev_chol_panel": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
+    "gpx_dev_chol_panel_next": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_adopt_factor": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.c_void_p, ctypes.POINTER(_hp)]),
 }
 for _name, (_res, _args) in SIGNATURES.items():

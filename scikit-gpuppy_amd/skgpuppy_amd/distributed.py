@@ -94,9 +94,11 @@ def panel_cholesky(ops, layout, rank, comm):
         buf, work = inflight
         ops.adopt_panel(p, buf, work)
         nxt = p + 1
-        if nxt < P:
-            inflight = post(nxt, p)          # the owner of the next panel updates + factors it first, off the main stream
+        # host order: the (single, cheap to queue) trailing update first, then the next panel's long chain of small
+        # launches -- on the device they run side by side on their own streams, ordered by events only
         ops.update_panels([q for q in mine if q > nxt], p)
+        if nxt < P:
+            inflight = post(nxt, p)          # the owner of the next panel updates + factors it off the main stream
     return comm.max_int(ops.finish())
 
 
@@ -132,7 +134,7 @@ class TorchComm(object):
 
     def broadcast(self, buf, src, ops=None):
         dist = self.dist
-        ctx = ops.comm_stream_context(src == self.rank) if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
+        ctx = ops.comm_stream_context() if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
         with ctx:
             n = buf.numel()
             if self.world == 1:
@@ -217,7 +219,11 @@ class GpxOps(object):
         self.theta = np.ascontiguousarray(theta, dtype=np.float64)
         with np.errstate(divide="ignore"):
             self.vt = float(np.exp(self.theta[1])) + jitter
+        self.v = float(np.exp(self.theta[0]))
         self.jitter = jitter
+        # inputs scaled by sqrt(w) once: every owned panel's Gram block is then a single asynchronous launch
+        sw = torch.as_tensor(np.sqrt(np.exp(self.theta[2:2 + self.d])), device=device)
+        self.xw = (x_dev * sw[None, :]).contiguous()
         npad, nblk = layout.npad, layout.nblk
         self.L = torch.empty((npad, npad), dtype=torch.float64, device=device)
         self.Dinv = torch.empty((nblk, TILE, TILE), dtype=torch.float64, device=device)
@@ -229,8 +235,6 @@ class GpxOps(object):
         self._operand = {}                              # panel -> (device pointer, leading dimension, first row) of its update operand
         self._ev_avail = {}                             # panel -> event: message complete (recorded on main)
         self._ev_main_done = {}                         # panel -> event: main's updates with that panel are queued
-        self._ev_side_done = [None, None]               # slot -> event: side stream is done reading the slot
-        self._side_has_work = False
 
     # ---- helpers ------------------------------------------------------------------------------
     def _stream_ptr(self, st):
@@ -256,10 +260,11 @@ class GpxOps(object):
         b = a + (b1 - b0) * TILE * TILE
         return buf[:a].view(rows, w), buf[a:b].view(b1 - b0, TILE, TILE), buf[b:b + w]
 
-    def comm_stream_context(self, is_source):
-        """the stream a broadcast is posted from: the side stream on the panel's owner (the message is packed there),
-        the main stream elsewhere (ordered behind the last updates that read the receive buffer)"""
-        return self.torch.cuda.stream(self.side if is_source and self._side_has_work else self.main)
+    def comm_stream_context(self):
+        """the stream every broadcast is posted from: the side stream -- on the owner the message is packed there, elsewhere
+        the receive is ordered there behind the last readers of its buffer (recv_buffer) and overlaps with the main
+        stream's trailing updates"""
+        return self.torch.cuda.stream(self.side)
 
     def sync_for_host(self):
         self.side.synchronize()
@@ -274,10 +279,10 @@ class GpxOps(object):
             self.L[c0:, c0:c0 + w].zero_()
             self.L[c0:c0 + w, c0:c0 + w].fill_diagonal_(1.0)
             return
-        xi = ctypes.c_void_p(self.x.data_ptr() + 8 * c0 * d)
-        st = self.lib.gpx_dev_gram(xi, n - c0, xi, min(c0 + w, n) - c0, d, self._gpx.ptr(self.theta), self.vt, 0, 1,
-                                   self._Lptr(c0, c0), npad, npad - c0, w, self._stream_ptr(self.main))
-        self._gpx.check(st, "gpx_dev_gram(panel %d)" % p)
+        xi = ctypes.c_void_p(self.xw.data_ptr() + 8 * c0 * d)
+        st = self.lib.gpx_dev_gram_scaled(xi, n - c0, xi, min(c0 + w, n) - c0, d, self.v, self.vt, 0, 1,
+                                          self._Lptr(c0, c0), npad, npad - c0, w, self._stream_ptr(self.main))
+        self._gpx.check(st, "gpx_dev_gram_scaled(panel %d)" % p)
 
     def _gemm(self, q0, q1, p, stream):
         """C[rows >= q0, columns q0..q1) -= P[rows >= q0] P[rows q0..q1)^T with P = the update operand of panel p"""
@@ -293,15 +298,20 @@ class GpxOps(object):
     def factor_panel(self, p, prev):
         b0, b1, c0, w, rows = self._geom(p)
         torch = self.torch
-        self._side_has_work = True
         with torch.cuda.stream(self.side):
             if prev is not None:
                 self.side.wait_event(self._ev_avail[prev])        # panel `prev` has arrived
-                self._gemm(c0, c0 + w, prev, self.side)
+                # update with `prev` + factorisation in one native call: square first (the chain starts at once), the rows
+                # below on the library's side stream ahead of their column solves
+                ptr, ldp, first = self._operand[prev]
+                _pb0, _pb1, _pc0, wp, _prows = self._geom(prev)
+                st = self.lib.gpx_dev_chol_panel_next(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1,
+                                                      ctypes.c_void_p(ptr + 8 * (c0 - first) * ldp), ldp, wp, self._p(self.Dinv),
+                                                      self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
             else:
                 self.side.wait_stream(self.main)                  # the panel has been assembled on the main stream
-            st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
-                                             self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
+                st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
+                                                 self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
             self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
             buf = self._slot(p)
             if self.layout.world > 1:
@@ -317,12 +327,10 @@ class GpxOps(object):
         return buf
 
     def recv_buffer(self, p):
-        # posted from the main stream: ordered behind main's reads of this slot (panel p - 2); the side stream's reads
-        # of it (copy into L, update of an owned next panel) are joined explicitly
-        ev = self._ev_side_done[p % 2]
-        if ev is not None:
-            self.main.wait_event(ev)
-        self._side_has_work = False
+        # the receive is posted from the side stream: behind the side stream's own reads of this slot (copy of panel p - 2
+        # into L, update of an owned panel p - 1 with it) and, through the event, behind the main stream's updates with it
+        if p - 2 in self._ev_main_done:
+            self.side.wait_event(self._ev_main_done[p - 2])
         return self._slot(p)
 
     def adopt_panel(self, p, buf, work):
@@ -359,9 +367,7 @@ class GpxOps(object):
         ev = self.torch.cuda.Event()
         ev.record(self.main)
         self._ev_main_done[p] = ev
-        es = self.torch.cuda.Event()
-        es.record(self.side)
-        self._ev_side_done[p % 2] = es
+        self._ev_main_done.pop(p - 3, None)
         self._operand.pop(p - 2, None)
 
     def finish(self):
