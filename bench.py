@@ -265,11 +265,11 @@ def run_single(args):
 
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (same workload)
-        with open(os.path.join(ROOT, "profiles", "r02_v1_pmc_traffic.json")) as fpm:
+        with open(os.path.join(ROOT, "profiles", "r02_v2_pmc_traffic.json")) as fpm:
             pm = json.load(fpm)
         if (args.workload or "c3") == "c3":
             traffic = pm["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r02_v1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
+            traffic_src = "profiles/r02_v2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction)"
     except Exception:
         pass
     out = {
