@@ -67,13 +67,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
     const int wave = t >> 6, lane = t & 63;
     const int fr = lane & 15, fq = lane >> 4;
 
-#ifdef GPX_LEAF_STAMP
-    long long stamp[6];
-    stamp[0] = wall_clock64();
-#define GPX_STAMP(k) stamp[k] = wall_clock64()
-#else
-#define GPX_STAMP(k)
-#endif
     if (t == 0) bad_s = 0;
     {   // thread t carries element (t>>4, t&15) of every 16x16 block: 36 independent loads in flight, then 36 LDS stores
         const int r = t >> 4, c = t & 15;
@@ -86,7 +79,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
         for (int b = 0; b < 36; ++b) X[b * XB + r * 17 + c] = v[b];
     }
     __syncthreads();
-    GPX_STAMP(1);
 
 #pragma unroll 1
     for (int jb = 0; jb < 8; ++jb) {
@@ -193,7 +185,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
     }
 
     // L -> global (zeros above the diagonal), diagonal, status
-    GPX_STAMP(2);
     {
         const int r = t >> 4, c = t & 15;
 #pragma unroll
@@ -215,7 +206,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
     }
     __syncthreads();
 
-    GPX_STAMP(3);
     // inverse, levels s = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
     for (int s = 1; s <= 4; s <<= 1) {
         const int npairs = 8 / (2 * s);
@@ -281,7 +271,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
         }
         __syncthreads();
     }
-    GPX_STAMP(4);
     {
         const int r = t >> 4, c = t & 15;
 #pragma unroll
@@ -290,13 +279,6 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
             for (int bj = 0; bj < 8; ++bj)
                 dinv[(16 * bi + r) * TILE + 16 * bj + c] = (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0;
     }
-#ifdef GPX_LEAF_STAMP
-    __syncthreads();
-    stamp[5] = wall_clock64();
-    if (t == 0)
-        for (int k = 0; k < 6; ++k) dinv[16 + k] = (double)(stamp[k] - stamp[0]);   // diagnostic build only: lands in the zero block
-#endif
-#undef GPX_STAMP
 #undef bad_s
 }
 

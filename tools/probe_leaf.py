@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Leaf kernel (potrf128 + trtri128 in one launch): correctness against numpy and stand-alone latency.
-GPX_LEAF=0 selects the register kernel, GPX_LEAF=1 (default) the blocked MFMA kernel."""
+"""Leaf kernel (potrf128 + trtri128 in one launch, MFMA out of LDS): correctness against numpy and stand-alone latency."""
 import ctypes
 import os
 import sys
@@ -27,11 +26,9 @@ def main():
     _gpx.check(_gpx.lib.gpx_dev_potrf_leaf(p(w), 128, p(dinv), p(diag), p(info), 0, st), "leaf")
     torch.cuda.synchronize()
     L = np.linalg.cholesky(A)
-    print("mode", os.environ.get("GPX_LEAF", "1"), "L err", np.abs(w.cpu().numpy() - L).max(), "inv err",
+    print("L err", np.abs(w.cpu().numpy() - L).max(), "inv err",
           np.abs(dinv.cpu().numpy() - np.linalg.inv(L)).max() / np.abs(np.linalg.inv(L)).max(), "diag err",
           np.abs(diag.cpu().numpy() - np.diag(L)).max(), "info", int(info[0]))
-    if os.environ.get("GPX_LEAF_STAMP"):
-        print("  stamps (10 ns ticks since kernel start: load, panels, L store, diag copy, levels, end):", dinv[0, 16:22].cpu().numpy())
     ws = [a.clone() for _ in range(50)]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for rep in range(2):
