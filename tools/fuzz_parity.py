@@ -10,7 +10,7 @@ from oracle import oracle as orc
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 150
-sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 500, 640, 1023, 1024, 1025, 1100, 1500, 2047, 2050]
+sizes = [1, 2, 3, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 500, 640, 1023, 1024, 1025, 1100, 1500, 2047, 2050, 2300, 3073]
 worst = dict(mean=0.0, var=0.0, approx=0.0, exact=0.0)
 for c in range(ncase):
     N = int(rng.choice(sizes)) if rng.rand() < 0.7 else int(rng.randint(1, 1300))
@@ -38,8 +38,20 @@ for c in range(ncase):
         ea = max(abs(a[0] - oa[0]), abs(a[1] - oa[1]) / sv); ee = max(abs(e[0] - oe[0]), abs(e[1] - oe[1]) / sv)
         worst["approx"] = max(worst["approx"], ea); worst["exact"] = max(worst["exact"], ee)
         ok = ok and ea < 1e-6 and ee < 1e-6
+    # the few-vector solver and the sampler's L z on random right-hand sides (gpx_solve / gpx_chol_mul)
+    nr = int(rng.choice([1, 3, 16, 17, 33]))
+    B = rng.randn(nr, N)
+    kb = gp._dev().solve(B)
+    ko = og.Kinv.dot(B.T).T
+    es = np.abs(kb - ko).max() / max(1e-300, np.abs(ko).max())
+    Lz = gp._dev().chol_mul(B)
+    with np.errstate(divide="ignore"):
+        Lo = np.linalg.cholesky(orc.gram(x, theta))
+    el = np.abs(Lz - B.dot(Lo.T)).max() / max(1e-300, np.abs(Lz).max())
+    worst["solve"] = max(worst.get("solve", 0.0), es); worst["chol_mul"] = max(worst.get("chol_mul", 0.0), el)
+    ok = ok and es < 1e-6 and el < 1e-9
     if not ok:
-        print("MISMATCH case", c, "N", N, "d", d, "M", M, "theta", theta, em, ev)
+        print("MISMATCH case", c, "N", N, "d", d, "M", M, "theta", theta, em, ev, es, el)
         sys.exit(1)
     gp._dev().close()
 print("fuzz ok: %d cases, worst abs deviations (variances relative to v): %s" % (ncase, worst))
