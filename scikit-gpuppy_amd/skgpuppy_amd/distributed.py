@@ -131,6 +131,7 @@ class TorchComm(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.split_bytes = split_bytes
+        self._split_ok = os.environ.get("GPX_PANEL_BROADCAST", "split") != "plain"   # "plain": one dist.broadcast per panel
 
     def broadcast(self, buf, src, ops=None):
         dist = self.dist
@@ -144,10 +145,16 @@ class TorchComm(object):
             parts = list(buf.view(self.world, n // self.world).unbind(0))
             mine = parts[self.rank]
             if dist.get_backend(self.group) == "nccl":
-                # both collectives are queued on RCCL's stream in this order; in-place all-gather of the rank's own part
-                w1 = dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group, async_op=True)
-                w2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
-                return _Work([w1, w2])
+                if self._split_ok:
+                    try:
+                        # both collectives are queued on RCCL's stream in this order
+                        w1 = dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group, async_op=True)
+                        w2 = dist.all_gather_into_tensor(buf, mine.clone(), group=self.group, async_op=True)
+                        return _Work([w1, w2])
+                    except (RuntimeError, ValueError, TypeError) as exc:   # argument validation: the same on every rank
+                        self._split_ok = False
+                        sys.stderr.write("[skgpuppy_amd.distributed] scatter + all-gather unavailable (%s): plain broadcast\n" % exc)
+                return _Work([dist.broadcast(buf, src=src, group=self.group, async_op=True)])
             # CPU backends (gloo rehearsal) do not order two asynchronous collectives: run them one after the other
             dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group)
             return _Work([dist.all_gather(parts, mine.clone(), group=self.group, async_op=True)])
