@@ -124,13 +124,14 @@ class TorchComm(object):
     2 (R-1)/R of the message per link instead of the whole message hopping round a ring (xGMI is
     point-to-point, a ring broadcast is per-link bound)."""
 
-    def __init__(self, group=None, split_bytes=8 << 20):
+    def __init__(self, group=None, split_bytes=8 << 20, exercise_single_rank=False):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.split_bytes = split_bytes
+        self.exercise_single_rank = exercise_single_rank     # tests: issue the collectives even in a group of one rank
         self._split_ok = os.environ.get("GPX_PANEL_BROADCAST", "split") != "plain"   # "plain": one dist.broadcast per panel
 
     def broadcast(self, buf, src, ops=None):
@@ -138,7 +139,7 @@ class TorchComm(object):
         ctx = ops.comm_stream_context() if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
         with ctx:
             n = buf.numel()
-            if self.world == 1:
+            if self.world == 1 and not self.exercise_single_rank:
                 return _Work([])
             if n * buf.element_size() < self.split_bytes or n % self.world:
                 return _Work([dist.broadcast(buf, src=src, group=self.group, async_op=True)])

@@ -494,6 +494,14 @@ for i in range(2):
     eg = gp.propagate_exact_sharded(us[i], Ss[i])
     assert abs(eg[0] - ew[0]) < 1e-9 and abs(eg[1] - ew[1]) < 1e-9
 gp.close()
+# the panel transport's collectives (scatter + all_gather_into_tensor, and the plain broadcast) accepted by RCCL: a group of one
+# rank normally skips them
+from skgpuppy_amd.distributed import TorchComm
+for comm in (TorchComm(split_bytes=1, exercise_single_rank=True), TorchComm(split_bytes=1 << 60, exercise_single_rank=True)):
+    g2 = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=comm)
+    m2, v2 = g2.estimate_many(xs)
+    assert np.abs(m2 - m1).max() < 1e-10 and np.abs(v2 - v1).max() < 1e-10 and comm._split_ok
+    g2.close()
 # a tight cluster with vt = 0: K is numerically indefinite -> the single-GPU fit takes the +1e-5 jitter, and so must the sharded one
 xd = rng.uniform(0, 1e-4, (600, d)); td = rng.randn(600); xs = rng.uniform(0, 1e-4, (77, d))
 th2 = np.array([0.0, -np.inf] + [0.0] * d)
