@@ -330,25 +330,20 @@ class SPGPCovariance(Covariance):
         return cached[1].cross(a, b)
 
     def cov_matrix(self, x, theta):
-        """Q_N + diag(K_N - Q_N) + vt I (Covariance.py:814-833)."""
-        model = self._model(x, None, theta)
-        try:
-            return model.dense(0)
-        finally:
-            model.close()
+        """Q_N + diag(K_N - Q_N) + vt I (Covariance.py:814-833); shares the device model of (x, theta) with inv_cov_matrix."""
+        return self._fit_model(x, None, theta).dense(0)
 
     def inv_cov_matrix(self, x, theta, cov_matrix=None):
         """the Woodbury inverse (Covariance.py:835-863); `cov_matrix` is ignored as in the reference."""
-        model = self._model(x, None, theta)
-        try:
-            return model.dense(1)
-        finally:
-            model.close()
+        return self._fit_model(x, None, theta).dense(1)
 
     def _fit_model(self, x, t, theta):
         """the device model of (x, t, theta), kept until the next different request: L-BFGS asks for the likelihood and
         its gradient at the same theta, one after the other"""
-        key = (id(x), id(t), _gpx.f64(theta).tobytes())
+        xa = np.asarray(x)
+        # identity of the arrays, plus their content while that is cheap to hash (an array mutated in place keeps its id)
+        sig = (hash(xa.tobytes()), None if t is None else hash(np.asarray(t).tobytes())) if xa.size <= (1 << 20) else None
+        key = (id(x), id(t), sig, _gpx.f64(theta).tobytes())
         cached = getattr(self, "_fit_cache", None)
         if cached is None or cached[0] != key:
             if cached is not None:
