@@ -30,6 +30,8 @@ struct gpx_spgp {
     double *Wt = nullptr;    // [mpad, npad] scratch: a row-scaled transpose of K_NM or Z
     double *LM = nullptr, *DinvM = nullptr, *diagM = nullptr;   // chol(K_M + 1e-5 I)
     double *LB = nullptr, *DinvB = nullptr, *diagB = nullptr;   // chol(B + 1e-5 I)
+    double *scrA = nullptr, *scrB = nullptr;   // [mpad, mpad] scratch: explicit inverse factors
+    double *LinvM = nullptr, *LinvB = nullptr; // [mpad, mpad] inv(L_M), inv(L_B) (lower): the predictor's two solves are GEMMs
     double *lam = nullptr;   // [npad] lambda_n
     double *ilam = nullptr;  // [npad] 1/sqrt(lambda_n), 0 in the padding
     double *va = nullptr, *vb = nullptr, *vc = nullptr;         // [npad] vector scratch
@@ -86,7 +88,7 @@ static int spgp_wtw(gpx_spgp *h, const double *W, double *C, double beta, double
     return 0;
 }
 
-// out[j][i] = in[i][j] * scale[i]   (in: [rows, ldin] -> out: [cols, ldout]; 32x32 LDS tiles)
+// out[j][i] = in[i][j] * scale[i]   (in: [rows, ldin] -> out: [cols, ldout]; 32x32 LDS tiles; scale == nullptr: plain transpose)
 __global__ __launch_bounds__(256) void scale_transpose_kernel(const double *__restrict__ in, long ldin, long rows, long cols,
                                                              const double *__restrict__ scale, double *__restrict__ out, long ldout)
 {
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void scale_transpose_kernel(const double *__re
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int r = ty; r < 32; r += 8) {
         const long i = r0 + r, j = c0 + tx;
-        tile[r][tx] = (i < rows && j < cols) ? in[i * ldin + j] * scale[i] : 0.0;
+        tile[r][tx] = (i < rows && j < cols) ? in[i * ldin + j] * (scale ? scale[i] : 1.0) : 0.0;
     }
     __syncthreads();
     for (int r = ty; r < 32; r += 8) {
@@ -178,7 +180,7 @@ extern "C" void gpx_spgp_free(gpx_spgp *h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void *bufs[] = {h->xw, h->xbw, h->sw, h->t, h->Knm, h->Z, h->Wt, h->LM, h->DinvM, h->diagM, h->LB, h->DinvB, h->diagB, h->lam,
+    void *bufs[] = {h->xw, h->xbw, h->sw, h->t, h->Knm, h->Z, h->Wt, h->LM, h->DinvM, h->diagM, h->LB, h->DinvB, h->diagB, h->scrA, h->scrB, h->LinvM, h->LinvB, h->lam,
                     h->ilam, h->va, h->vb, h->vc, h->ma, h->mb, h->mzero, h->beta, h->mscr, h->outd};
     for (void *p : bufs) dfree(p);
     if (h->info) dfree(h->info);
@@ -203,11 +205,29 @@ static int spgp_chol_km(gpx_spgp *h, double jitter, double *L, double *Dinv, dou
     return 0;
 }
 
-// Z <- K_NM L^-T
-static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv)
+// out <- inv(L) (lower, row-major): inv(L)^T by the structured recursion of the dense path, then its transpose.
+// scrA is used; out must not be scrA (it also receives, first, the product inv(L)^T inv(L) the helper forms).
+static int spgp_linv(gpx_spgp *h, const double *L, const double *Dinv, double *out)
 {
-    GPX_HIP(hipMemcpyAsync(h->Z, h->Knm, sizeof(double) * h->npad * h->mpad, hipMemcpyDeviceToDevice, h->stream));
-    return trsm_right_lt(h->Z, h->mpad, h->npad, L, h->mpad, Dinv, 0, h->mblk, h->stream, nullptr);
+    hipStream_t s = h->stream;
+    const int64_t mp = h->mpad;
+    GPX_TRY(build_kinv_from_factor(L, mp, h->mblk, Dinv, h->scrA, out, s, nullptr));
+    dim3 grid((unsigned)((mp + 31) / 32), (unsigned)((mp + 31) / 32));
+    hipLaunchKernelGGL(scale_transpose_kernel, grid, dim3(256), 0, s, (const double *)h->scrA, (long)mp, (long)mp, (long)mp, (const double *)nullptr,
+                       out, (long)mp);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// Z <- K_NM L^-T as ONE product with the explicit inverse: inv(L) (M x M, lower) is cheap next to the N M^2 solve, and
+// K_NM inv(L)^T is a K = M GEMM on 128 x 128 tiles that skips the zero triangle of the inverse (70 TFLOP/s) where the
+// recursive TRSM issues M / 128 leaf products and short-K updates over N rows (45-50 TFLOP/s) after a 4 GB copy of K_NM.
+static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv, double *linv_keep = nullptr)
+{
+    double *linv = linv_keep ? linv_keep : h->scrB;
+    GPX_TRY(spgp_linv(h, L, Dinv, linv));
+    return launch_gemm_nt(h->Knm, h->mpad, linv, h->mpad, h->Z, h->mpad, h->npad, h->mpad, h->mpad, 1.0, 0.0, 0, h->stream, nullptr, 0, 0,
+                          GEMM_TRI_B_LOWER);
 }
 
 static int spgp_transpose(gpx_spgp *h, const double *src, const double *row_scale, double *dst)
@@ -232,6 +252,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(dalloc(&h->Knm, np * mp)); GPX_TRY(dalloc(&h->Z, np * mp)); GPX_TRY(dalloc(&h->Wt, mp * np));
     GPX_TRY(dalloc(&h->LM, mp * mp)); GPX_TRY(dalloc(&h->DinvM, tt)); GPX_TRY(dalloc(&h->diagM, mp));
     GPX_TRY(dalloc(&h->LB, mp * mp)); GPX_TRY(dalloc(&h->DinvB, tt)); GPX_TRY(dalloc(&h->diagB, mp));
+    GPX_TRY(dalloc(&h->scrA, mp * mp)); GPX_TRY(dalloc(&h->scrB, mp * mp)); GPX_TRY(dalloc(&h->LinvM, mp * mp)); GPX_TRY(dalloc(&h->LinvB, mp * mp));
     GPX_TRY(dalloc(&h->lam, np)); GPX_TRY(dalloc(&h->ilam, np)); GPX_TRY(dalloc(&h->va, np)); GPX_TRY(dalloc(&h->vb, np)); GPX_TRY(dalloc(&h->vc, np));
     GPX_TRY(dalloc(&h->ma, mp)); GPX_TRY(dalloc(&h->mb, mp)); GPX_TRY(dalloc(&h->mzero, mp)); GPX_TRY(dalloc(&h->beta, mp)); GPX_TRY(dalloc(&h->mscr, mp));
     GPX_TRY(dalloc(&h->outd, 8));
@@ -265,7 +286,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(spgp_chol_km(h, 1e-5, h->LM, h->DinvM, h->diagM, &info));
     if (info > 0) { gpx_set_error("K_M + 1e-5 I is not positive definite (leading minor %d)", info); return info; }
     // Z = K_NM L_M^-T ; lambda = diag(K_N - Q_N) + vt = v + vt - |Z_n|^2     (:847-853)
-    GPX_TRY(spgp_solve_into_z(h, h->LM, h->DinvM));
+    GPX_TRY(spgp_solve_into_z(h, h->LM, h->DinvM, h->LinvM));
     GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->lam, s, nullptr));
     GPX_TRY(vec_op(VEC_INV_SQRT, n, np, 0.0, h->lam, nullptr, h->ilam, nullptr, s));
     // W^T = (Lambda^-1/2 K_NM)^T ;  B~ = K_M + 1e-5 I + W^T W                   (:856-858)
@@ -277,6 +298,7 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     if (info > 0) { gpx_set_error("B + 1e-5 I is not positive definite (leading minor %d)", info); return info; }
+    GPX_TRY(spgp_linv(h, h->LB, h->DinvB, h->LinvB));   // the predictor's second solve
     // r = K_MN Lambda^-1 t = W^T (Lambda^-1/2 t) ;  beta = B~^-1 r             (commented estimate, :781-784)
     GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->ilam, h->va, nullptr, s));
     GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->va, 0.0, h->ma, h->mb, s, nullptr));
@@ -322,9 +344,10 @@ extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, doubl
     const int d = h->d;
     const int64_t mp = h->mpad;
     const int64_t chunk = std::min<int64_t>(round_up(ms, TILE), 65536);
-    double *xq = nullptr, *xqw = nullptr, *Ka = nullptr, *Kb = nullptr, *o = nullptr;
+    double *xq = nullptr, *xqw = nullptr, *Ka = nullptr, *Kb = nullptr, *Kc = nullptr, *o = nullptr;
     auto body = [&]() -> int {
         GPX_TRY(dalloc(&xq, chunk * d)); GPX_TRY(dalloc(&xqw, chunk * d)); GPX_TRY(dalloc(&Ka, chunk * mp)); GPX_TRY(dalloc(&Kb, chunk * mp));
+        GPX_TRY(dalloc(&Kc, chunk * mp));
         GPX_TRY(dalloc(&o, 5 * chunk));
         double *mean = o, *unused = o + chunk, *va = o + 2 * chunk, *vb = o + 3 * chunk, *var = o + 4 * chunk;
         for (int64_t q0 = 0; q0 < ms; q0 += chunk) {
@@ -332,12 +355,12 @@ extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, doubl
             GPX_HIP(hipMemcpyAsync(xq, xs + q0 * d, sizeof(double) * qc * d, hipMemcpyDefault, s));
             GPX_TRY(launch_scale_rows(xq, qc, qp, d, h->sw, xqw, s));
             GPX_TRY(launch_gram(xqw, qc, h->xbw, h->m, d, h->v, 0.0, 0, 1, Ka, mp, qp, mp, s, nullptr));   // K_*M
-            GPX_HIP(hipMemcpyAsync(Kb, Ka, sizeof(double) * qp * mp, hipMemcpyDeviceToDevice, s));
             GPX_TRY(launch_predict_reduce(Ka, mp, qc, mp, h->beta, 0.0, mean, unused, s, nullptr));       // K_*M beta
-            GPX_TRY(trsm_right_lt(Ka, mp, qp, h->LM, mp, h->DinvM, 0, h->mblk, s, nullptr));
-            GPX_TRY(trsm_right_lt(Kb, mp, qp, h->LB, mp, h->DinvB, 0, h->mblk, s, nullptr));
-            GPX_TRY(launch_predict_reduce(Ka, mp, qc, mp, h->mzero, h->v + h->vt, unused, va, s, nullptr));   // v + vt - |K_*M L_M^-T|^2
-            GPX_TRY(launch_predict_reduce(Kb, mp, qc, mp, h->mzero, 0.0, unused, vb, s, nullptr));            //        - |K_*M L_B^-T|^2
+            // K_*M L^-T for both factors: one product each with the explicit inverse (zero triangle skipped)
+            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvM, mp, Kb, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_LOWER));
+            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvB, mp, Kc, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_LOWER));
+            GPX_TRY(launch_predict_reduce(Kb, mp, qc, mp, h->mzero, h->v + h->vt, unused, va, s, nullptr));   // v + vt - |K_*M L_M^-T|^2
+            GPX_TRY(launch_predict_reduce(Kc, mp, qc, mp, h->mzero, 0.0, unused, vb, s, nullptr));            //        - |K_*M L_B^-T|^2
             GPX_TRY(vec_op(VEC_SUB, qc, qc, 0.0, va, vb, var, nullptr, s));
             GPX_HIP(hipMemcpyAsync(mean_out + q0, mean, sizeof(double) * qc, hipMemcpyDefault, s));
             GPX_HIP(hipMemcpyAsync(var_out + q0, var, sizeof(double) * qc, hipMemcpyDefault, s));
@@ -347,7 +370,7 @@ extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, doubl
     };
     const int rc = body();
     (void)hipStreamSynchronize(s);
-    dfree(xq); dfree(xqw); dfree(Ka); dfree(Kb); dfree(o);
+    dfree(xq); dfree(xqw); dfree(Ka); dfree(Kb); dfree(Kc); dfree(o);
     return rc;
 }
 
@@ -599,11 +622,11 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         GPX_TRY(spgp_wtw(h, W2, Qb, 1.0, -1.0));
         GPX_TRY(launch_symmetrize_lower(Qb, mp, mp, s));
         hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
-        // L^-T (explicit, upper triangular) -> Scr ; Y doubles as the K_M^-1 the helper also writes
-        GPX_TRY(build_kinv_from_factor(L, mp, h->mblk, Dinv, Scr, Y, s, nullptr));
-        GPX_TRY(launch_gemm_nt(T, mp, Scr, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Z = Kbar^T = Vbar^T L^-1
-        GPX_TRY(launch_gemm_nt(Scr, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));       // Y = L^-T Qb   (Qb symmetric)
-        GPX_TRY(launch_gemm_nt(Y, mp, Scr, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Qbar = L^-T Qb L^-1
+        // L^-T (explicit, upper triangular) is still in scrA from spgp_solve_into_z above
+        const double *LinvT = h->scrA;
+        GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Z = Kbar^T = Vbar^T L^-1
+        GPX_TRY(launch_gemm_nt(LinvT, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Y = L^-T Qb   (Qb symmetric)
+        GPX_TRY(launch_gemm_nt(Y, mp, LinvT, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Qbar = L^-T Qb L^-1
         GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 0.0, 0, 1, Qk, mp, mp, mp, s, nullptr)); // K_M (no jitter), zero padded
         GPX_TRY(spgp_epass(h, h->Z, h->Knm, np, h->xw, part, PEd));
         GPX_TRY(spgp_epass(h, Qbar, Qk, mp, h->xbw, part, PFd));
