@@ -153,7 +153,8 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                    hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0, int tri = 0);
 // batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
 // tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
-enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3, GEMM_TRI_B_LOWER_PAIRED = 4 /* internal */ };
+enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3, GEMM_TRI_B_LOWER_PAIRED = 4 /* internal */,
+       GEMM_TRI_B_UPPER = 5, GEMM_TRI_B_UPPER_PAIRED = 6 /* internal */ };
 struct GemmBatch { int nq; long sp, sq; int tri; };
 int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
                            GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);

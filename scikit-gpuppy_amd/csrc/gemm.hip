@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         // ktrim: tiles of very different length (see below) -- deal them round-robin, longest first, instead of a chunk per XCD
         const int lid = ktrim ? orig : xcd_chunk_start(nwg, orig & 7) + (orig >> 3);
         if (LOWER) lower_tile(lid, tri_off, tri_rows, by, bx);
-        else if (!ba.nq && ba.tri == GEMM_TRI_B_LOWER_PAIRED) {
+        else if (!ba.nq && (ba.tri == GEMM_TRI_B_LOWER_PAIRED || ba.tri == GEMM_TRI_B_UPPER_PAIRED)) {
             // column tiles bx and (ncols - 1 - bx) of one row tile go to the same workgroup (tri_off = ncols): every
             // workgroup contracts over (ncols + 1) * BTN -- equal work, and half as many workgroups to place
             bx = blockIdx.x;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     // Rectangular launches: A alone is upper triangular with its diagonal shifted by ktrim - 1 columns to the left of its
     // first column (the triangular inverse's update  Z[:, right] -= Z[:, left] L21^T): row tile by starts at
     // k = max(0, by * BTM - (ktrim - 1)).
-    const int nrep = (!ba.nq && ba.tri == GEMM_TRI_B_LOWER_PAIRED) ? 2 : 1;
+    const int nrep = (!ba.nq && (ba.tri == GEMM_TRI_B_LOWER_PAIRED || ba.tri == GEMM_TRI_B_UPPER_PAIRED)) ? 2 : 1;
     for (int rep = 0; rep < nrep; ++rep) {
         if (rep) bx = tri_off - 1 - bx;   // (nothing reads the staging buffers after a tile's last barrier: the next tile may start at once)
         long kstart = 0;
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         if (ba.tri == GEMM_TRI_A_UPPER) kstart = (long)by * BTM;                       // A[i][k] = 0 for k < i
         else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
         else if (ba.tri == GEMM_TRI_B_LOWER || ba.tri == GEMM_TRI_B_LOWER_PAIRED) kend = min(K, (bx + 1) * BTN);   // B[j][k] = 0 for k > j
+        else if (ba.tri == GEMM_TRI_B_UPPER || ba.tri == GEMM_TRI_B_UPPER_PAIRED) kstart = (long)bx * BTN;          // B[j][k] = 0 for k < j
         gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
     }
 }
@@ -325,7 +326,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         gpx_set_error("launch_gemm_nt: ktrim on a lower-only launch needs a square C with K == M");
         return GPX_ERR_BAD_ARG;
     }
-    if (tri && (lower_only || ktrim || (tri == GEMM_TRI_B_LOWER ? K != N : K != M))) {
+    if (tri && (lower_only || ktrim || ((tri == GEMM_TRI_B_LOWER || tri == GEMM_TRI_B_UPPER) ? K != N : K != M))) {
         gpx_set_error("launch_gemm_nt: a triangular operand needs a plain launch with K equal to that operand's other dimension");
         return GPX_ERR_BAD_ARG;
     }
@@ -358,9 +359,9 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
                                (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, na_, nb_, nb_);                                  \
     } while (0)
-    if (tri == GEMM_TRI_B_LOWER && tiles >= SMALL_GRID_TILES && (N / TILE) % 2 == 0) {
-        // column tiles of length (bx + 1) * 128: pair bx with its mirror image so that every workgroup does the same work
-        const GemmBatch pa_ = {0, 0, 0, GEMM_TRI_B_LOWER_PAIRED};
+    if ((tri == GEMM_TRI_B_LOWER || tri == GEMM_TRI_B_UPPER) && tiles >= SMALL_GRID_TILES && (N / TILE) % 2 == 0) {
+        // column tiles of length (bx + 1) * 128 (resp. K - bx * 128): pair bx with its mirror image so that every workgroup does the same work
+        const GemmBatch pa_ = {0, 0, 0, tri == GEMM_TRI_B_LOWER ? GEMM_TRI_B_LOWER_PAIRED : GEMM_TRI_B_UPPER_PAIRED};
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
                            (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
     } else if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently

@@ -624,7 +624,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
         // L^-T (explicit, upper triangular) is still in scrA from spgp_solve_into_z above
         const double *LinvT = h->scrA;
-        GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Z = Kbar^T = Vbar^T L^-1
+        GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_UPPER));   // Z = Kbar^T = Vbar^T L^-1 (L^-T upper: half the contraction)
         GPX_TRY(launch_gemm_nt(LinvT, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Y = L^-T Qb   (Qb symmetric)
         GPX_TRY(launch_gemm_nt(Y, mp, LinvT, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Qbar = L^-T Qb L^-1
         GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 0.0, 0, 1, Qk, mp, mp, mp, s, nullptr)); // K_M (no jitter), zero padded
