@@ -272,7 +272,10 @@ int TriSolver::prepare(const double *L_, int64_t ld_, int64_t nblk_, const doubl
         return 0;
     };
     rc = body();
-    if (rc) release();
+    if (rc) {
+        (void)hipStreamSynchronize(s);   // launches already queued may still use the buffers
+        release();
+    }
     return rc;
 }
 
