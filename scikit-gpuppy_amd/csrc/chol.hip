@@ -56,6 +56,131 @@ __device__ __forceinline__ double bperm_f64(double v, int byte_index)
     return __hiloint2double(hi, lo);
 }
 
+// In-kernel stamps of the leaf's phases: only in the builder-side probe build (tools/native/probe_leafk.hip defines the macro
+// and includes this file); the library build contains none of it.
+#ifdef GPX_LEAF_STAMPS
+__device__ unsigned long long g_leaf_stamps[16];
+#define LEAF_STAMP(i) do { if (threadIdx.x == 0) g_leaf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define LEAF_STAMP_RT(i) do { if (threadIdx.x == 0) g_leaf_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define LEAF_ACC_BEGIN() unsigned long long acc_t_ = __builtin_amdgcn_s_memtime()
+#define LEAF_ACC(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_leaf_stamps[i] += n_ - acc_t_; acc_t_ = n_; } while (0)
+#else
+#define LEAF_STAMP(i) do { } while (0)
+#define LEAF_STAMP_RT(i) do { } while (0)
+#define LEAF_ACC_BEGIN() do { } while (0)
+#define LEAF_ACC(i) do { } while (0)
+#endif
+
+// shared tail of the leaf variants: L -> global, then the inverse of the factor in place (recursive doubling over the 16-blocks)
+__device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, double *diag_out, int *info, double *X, int *bad_sp)
+{
+#define bad_s (*bad_sp)
+    const int t = threadIdx.x;
+    const int wave = t >> 6, lane = t & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    LEAF_STAMP(4);
+    // L -> global (zeros above the diagonal), diagonal, status
+    {
+        const int r = t >> 4, c = t & 15;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 8; ++bj) {
+                double val = 0.0;
+                if (bj < bi) val = X[xblk(bi, bj) + r * 17 + c];
+                else if (bj == bi) val = (c <= r) ? X[xblk(bi, bi) + r * 17 + c] : 0.0;
+                A[(long)(16 * bi + r) * ld + 16 * bj + c] = val;
+                if (bj == bi && c == r) diag_out[16 * bi + r] = val;
+            }
+    }
+    if (t == 0 && bad_s && *info == 0) *info = bad_s;
+    __syncthreads();
+    for (int e = t; e < 8 * 256; e += 256) {
+        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        X[xblk(b, b) + r * 17 + c] = dinv[(16 * b + r) * TILE + 16 * b + c];
+    }
+    __syncthreads();
+
+    LEAF_STAMP(5);
+    // inverse, levels s = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
+    for (int s = 1; s <= 4; s <<= 1) {
+        const int npairs = 8 / (2 * s);
+        const int ntask = npairs * s * s;
+        v4d res[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                const int rb = 2 * s * p + s + i, cb = 2 * s * p;
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int k = j; k < s; ++k) {
+                    const double *Lk = &X[xblk(rb, cb + k) + fr * 17 + fq];                  // L21[i][k]: A[row fr][4kk + fq]
+                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // X11[k][j]: B[4kk + fq][col fr]
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
+                }
+                res[q] = acc;
+            }
+        }
+        __syncthreads();   // all L21 reads are done before T lands in the same slots
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                const int rb = 2 * s * p + s, cb = 2 * s * p;
+                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+                for (int k = 0; k <= i; ++k) {
+                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];
+                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
+                }
+                res[q] = acc;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int task = wave + 4 * q;
+            if (task < ntask) {
+                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
+                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
+            }
+        }
+        __syncthreads();
+    }
+    LEAF_STAMP(6);
+    {
+        const int r = t >> 4, c = t & 15;
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj < 8; ++bj)
+                dinv[(16 * bi + r) * TILE + 16 * bj + c] = (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0;
+    }
+    LEAF_STAMP(7);
+    LEAF_STAMP_RT(9);
+#undef bad_s
+}
+
 // X: packed lower blocks A -> L -> inverse (in place); Gs: inv(L_d)^T of the current panel.  The inverses of the eight
 // diagonal 16-blocks wait in their final place in `dinv` (global) until the factor has left the LDS: the leaf's footprint
 // stays at 80 KB, which fits next to one bulk GEMM workgroup (64 KB) on a CU with room to spare.
@@ -184,101 +309,7 @@ __device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv,
         __syncthreads();
     }
 
-    // L -> global (zeros above the diagonal), diagonal, status
-    {
-        const int r = t >> 4, c = t & 15;
-#pragma unroll
-        for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-            for (int bj = 0; bj < 8; ++bj) {
-                double val = 0.0;
-                if (bj < bi) val = X[xblk(bi, bj) + r * 17 + c];
-                else if (bj == bi) val = (c <= r) ? X[xblk(bi, bi) + r * 17 + c] : 0.0;
-                A[(long)(16 * bi + r) * ld + 16 * bj + c] = val;
-                if (bj == bi && c == r) diag_out[16 * bi + r] = val;
-            }
-    }
-    if (t == 0 && bad_s && *info == 0) *info = bad_s;
-    __syncthreads();
-    for (int e = t; e < 8 * 256; e += 256) {
-        const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        X[xblk(b, b) + r * 17 + c] = dinv[(16 * b + r) * TILE + 16 * b + c];
-    }
-    __syncthreads();
-
-    // inverse, levels s = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
-    for (int s = 1; s <= 4; s <<= 1) {
-        const int npairs = 8 / (2 * s);
-        const int ntask = npairs * s * s;
-        v4d res[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s + i, cb = 2 * s * p;
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = j; k < s; ++k) {
-                    const double *Lk = &X[xblk(rb, cb + k) + fr * 17 + fq];                  // L21[i][k]: A[row fr][4kk + fq]
-                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // X11[k][j]: B[4kk + fq][col fr]
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        __syncthreads();   // all L21 reads are done before T lands in the same slots
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s, cb = 2 * s * p;
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = 0; k <= i; ++k) {
-                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];
-                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
-            }
-        }
-        __syncthreads();
-    }
-    {
-        const int r = t >> 4, c = t & 15;
-#pragma unroll
-        for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-            for (int bj = 0; bj < 8; ++bj)
-                dinv[(16 * bi + r) * TILE + 16 * bj + c] = (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0;
-    }
+    leaf_finish(A, ld, dinv, diag_out, info, X, bad_sp);
 #undef bad_s
 }
 
@@ -292,11 +323,180 @@ __global__ __launch_bounds__(256) void potrf_trtri128_mfma_kernel(double *A, lon
     leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Gs, &bad_s);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Leaf, second formulation (the default): the 16-column panel step is a row-parallel LDL^T elimination with no
+// cross-lane traffic through LDS.  Lane = column c of the panel (16 lanes = one DPP row), registers = rows: a group of
+// 16 lanes holds the symmetric diagonal block (16 registers) plus one row of the appended identity and one row of each
+// block below (7 registers), the 16 groups of the workgroup covering all 128 rows.  Pivot j: the pivot and each row's
+// entry of column j come from lane j of the group by DPP row_newbcast folded into the multiply-add
+// (v_fmac_f64_dpp: x_i[c] -= x_i[j] * a[j][c] / d_j for c > j), one instruction per row.  The square roots leave the
+// dependent chain (a reciprocal per pivot; every lane scales its own column by rsqrt(d_c) once at the end), the
+// appended identity turns into inv(L_d)^T and the rows below into L_ib -- no separate triangular solve, no barrier
+// inside the panel, and every wave carries an equal share instead of wave 0 doing the pivoting alone.
+// Next to a saturating fp64-MFMA kernel each dependent VALU step of a leaf wave waits for a 64-cycle MFMA of the
+// co-resident wave: ~10 dependent steps per pivot here against ~25 before.
+// ------------------------------------------------------------------------------------------------
+template <int J> __device__ __forceinline__ double dpp_row_bcast(double v)
+{
+    double r;
+    // s_nop 1: a DPP read needs two wait states behind the VALU write of its source (invisible to hipcc's hazard pass)
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(J));
+    return r;
+}
+template <int J> __device__ __forceinline__ void fmac_row_bcast(double &x, double nw)
+{
+    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(nw), "n"(J));
+}
+
+template <int J> __device__ __forceinline__ void elim_pivot(double (&d)[16], double &gi, double (&b)[7], double &piv, int c)
+{
+    const double dj = dpp_row_bcast<J>(d[J]);
+    double r = __builtin_amdgcn_rcp(dj);
+    double e = fma(-dj, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-dj, r, 1.0);
+    r = fma(r, e, r);
+    const double nw = (c > J) ? -(d[J] * r) : 0.0;     // columns left of and at the pivot are final
+    piv = (c == J) ? dj : piv;
+#pragma unroll
+    for (int i = J + 1; i < 16; ++i) fmac_row_bcast<J>(d[i], nw);   // the next pivot's row first
+    fmac_row_bcast<J>(gi, nw);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) fmac_row_bcast<J>(b[q], nw);
+    if constexpr (J + 1 < 16) elim_pivot<J + 1>(d, gi, b, piv, c);
+}
+
+__device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
+                                               double *X, int *bad_sp)
+{
+#define bad_s (*bad_sp)
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int g = t >> 4, c = t & 15;       // row group (0..15) and column within the panel
+
+    LEAF_STAMP(0);
+    LEAF_STAMP_RT(8);
+#ifdef GPX_LEAF_STAMPS
+    if (t == 0) g_leaf_stamps[2] = g_leaf_stamps[3] = 0;
+#endif
+    if (t == 0) bad_s = 0;
+    {
+        double v[36];
+#pragma unroll
+        for (int bi = 0; bi < 8; ++bi)
+#pragma unroll
+            for (int bj = 0; bj <= bi; ++bj) v[bi * (bi + 1) / 2 + bj] = A[(long)(16 * bi + g) * ld + 16 * bj + c];
+#pragma unroll
+        for (int b = 0; b < 36; ++b) X[b * XB + g * 17 + c] = v[b];
+    }
+    __syncthreads();
+    LEAF_STAMP(1);
+    LEAF_ACC_BEGIN();
+
+#pragma unroll 1
+    for (int jb = 0; jb < 8; ++jb) {
+        {
+            double *Db = &X[xblk(jb, jb)];
+            double d[16], b[7], gi, piv = 1.0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) d[i] = Db[(i >= c) ? i * 17 + c : c * 17 + i];     // symmetric image from the lower triangle
+            gi = (c == g) ? 1.0 : 0.0;
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int ib = jb + 1 + q;
+                b[q] = (ib < 8) ? X[xblk(ib < 8 ? ib : 7, jb) + g * 17 + c] : 0.0;
+            }
+            elim_pivot<0>(d, gi, b, piv, c);
+            const double sc = fast_rsqrt(piv);           // lane c: 1 / L_cc
+            // a non-positive (or NaN) pivot: first such column of the first such panel
+            const unsigned long long badm = __builtin_amdgcn_ballot_w64(!(piv > 0.0)) & 0xffffull;
+            if (t == 0 && badm && bad_s == 0) bad_s = col_offset + 16 * jb + __builtin_ctzll(badm) + 1;
+            dinv[(16 * jb + c) * TILE + 16 * jb + g] = gi * sc;   // inv(L_d)[c][g]; exactly zero for c < g
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int ib = jb + 1 + q;
+                if (ib < 8) X[xblk(ib, jb) + g * 17 + c] = b[q] * sc;
+            }
+            if (fq == 0) {   // the first group of every wave stores the rows i = wave (mod 4) of the diagonal block
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if ((i & 3) == wave) Db[i * 17 + c] = (i >= c) ? d[i] * sc : 0.0;
+            }
+        }
+        __syncthreads();
+        LEAF_ACC(2);
+        // ---- trailing update: A[ib][kb] -= L[ib][jb] L[kb][jb]^T, jb < kb <= ib; two tasks in flight per wave ----
+        {
+            const int nb = 7 - jb;
+            const int ntask = nb * (nb + 1) / 2;
+            for (int task0 = wave; task0 < ntask; task0 += 8) {
+                v4d acc[2];
+                double *Cb[2];
+                double la[2][4], lb[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int task = task0 + 4 * u;
+                    const int tk = task < ntask ? task : task0;
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= tk) ++ii;           // row within the trailing triangle
+                    const int kk0 = tk - ii * (ii + 1) / 2;
+                    const int ib = jb + 1 + ii, kb = jb + 1 + kk0;
+                    Cb[u] = &X[xblk(ib, kb)];
+                    const double *La = &X[xblk(ib, jb) + fr * 17 + fq];
+                    const double *Lb = &X[xblk(kb, jb) + fr * 17 + fq];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[u][r] = Cb[u][(fq + 4 * r) * 17 + fr];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { la[u][kk] = -La[4 * kk]; lb[u][kk] = Lb[4 * kk]; }
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[u][kk], lb[u][kk], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (u == 0 || task0 + 4 < ntask)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) Cb[u][(fq + 4 * r) * 17 + fr] = acc[u][r];
+            }
+        }
+        __syncthreads();
+        LEAF_ACC(3);
+    }
+    leaf_finish(A, ld, dinv, diag_out, info, X, bad_sp);
+#undef bad_s
+}
+
+__global__ __launch_bounds__(256) void potrf_trtri128_elim_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
+                                                                 int col_offset, int prio)
+{
+    __shared__ __attribute__((aligned(16))) double X[36 * XB];
+    __shared__ int bad_s;
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    leaf_elim_body(A, ld, dinv, diag_out, info, col_offset, X, &bad_s);
+}
+
+static int leaf_prio()
+{
+    static const int v = [] { const char *e = getenv("GPX_LEAF_PRIO"); return e ? atoi(e) : 1; }();
+    return v;
+}
+static int leaf_variant()
+{
+    static const int v = [] { const char *e = getenv("GPX_LEAF"); return (e && e[0] == 'o') ? 0 : 1; }();   // GPX_LEAF=old: the bpermute formulation
+    return v;
+}
+
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
-    hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
+    if (leaf_variant())
+        hipLaunchKernelGGL(potrf_trtri128_elim_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset, leaf_prio());
+    else
+        hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -151,6 +151,9 @@ int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const dou
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
                    hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0, int tri = 0);
+// the same product on the small-footprint kernel that is placed at once next to a saturating bulk launch (gemm.hip)
+int launch_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t N,
+                          int64_t K, double alpha, double beta, hipStream_t s, Profiler *prof);
 // batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
 // tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
 enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3, GEMM_TRI_B_LOWER_PAIRED = 4 /* internal */,
