@@ -614,6 +614,7 @@ struct TopPipe {
     hipStream_t stream = nullptr;
     int64_t r0 = 0, r1 = 0;                 // block rows of the slice
     std::vector<hipEvent_t> *events = nullptr;   // owned by the caller, destroyed after the final synchronisation
+    int big = 0;                            // 3: tiles with the bulk kernel's register footprint (see the CU reservation in chol_factor)
 };
 
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
@@ -621,11 +622,14 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
 {
     double *Zt = L + (top->r0 * TILE) * ld;
     const int64_t M = (top->r1 - top->r0) * TILE;
+    // with CUs reserved for the chain these launches take the bulk kernel's 128 x 128 tiles (224 VGPRs): they must not
+    // settle on the reserved CUs, where the chain's own small kernels would then queue behind them
+    const int big = top->big;
     if (j > B0)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
-                               -1.0, 1.0, 0, top->stream, prof));
+                               -1.0, 1.0, 0, top->stream, prof, big));
     return launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0,
-                          top->stream, prof);
+                          top->stream, prof, big);
 }
 
 static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
@@ -638,6 +642,9 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
         if (rows_below > 0) {
             double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
             GPX_TRY(launch_gemm_nt(Z, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Z, ld, rows_below * TILE, TILE, TILE, 1.0, 0.0, 0, s, prof));
+            // right-looking inside the square.  (Left-looking -- only the next block column updated per step, <= 28 workgroups
+            // with K up to 896 -- was measured: a step then takes one workgroup's 24 us for a 32 x 128 x 896 tile instead of
+            // spreading K = 128 tiles over the chip; the chain of an idle chip went from 480 to 577 us per panel.)
             GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
                                    rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
         }
@@ -722,6 +729,54 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
     return rc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// CU reservation for the diagonal chain.  Measured (tools/native/probe_slot.hip, probe_leafk.hip, probe_sliver.py): while a bulk
+// launch saturates the chip (two workgroups per CU, 224 VGPRs per wave), a small kernel of the chain waits 40-130 us for a
+// retiring bulk workgroup's place -- equal-length tiles retire in bursts -- and then runs 3x (next to one bulk wave per SIMD)
+// to 10x (next to two) slower than alone; kernels small enough to be placed at once (<= 64 VGPRs, <= 16 KB of LDS) pay the
+// 10x.  Neither stream priorities nor s_setprio change that.  What does: a few CUs that the bulk cannot enter.  A "blocker"
+// workgroup of four sleeping waves that each hold 320 VGPRs leaves 192 registers per SIMD: no bulk wave (224) fits there, the
+// chain's kernels (leaf 144, 32/64-row GEMM tiles 80-122 VGPRs) do, and the whole LDS stays free.  R blockers launched on an
+// idle chip take R distinct CUs (two cannot share one), dealt round-robin over the XCDs; they leave when the flag is set (after
+// the last bulk launch of the factorisation) or, whatever happens to the host, when their time limit expires.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cu_blocker_kernel(const int *stop, int *placed, unsigned long long limit_ticks)
+{
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a63, 0" ::: "v255", "a63");   // 256 VGPRs + 64 AGPRs: 320 registers per wave
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(placed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 64) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+        while (__hip_atomic_load(stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 &&
+               __builtin_amdgcn_s_memrealtime() - t0 < limit_ticks)
+            __builtin_amdgcn_s_sleep(127);
+    }
+    __syncthreads();                                     // the other three waves wait here without issuing anything
+}
+
+__global__ void set_flag_kernel(int *flag, int value) { __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// holds its stream until `want` blockers have taken their CUs (or the time limit expires: the reservation is an optimisation)
+__global__ void wait_placed_kernel(const int *placed, int want, unsigned long long limit_ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(placed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want && __builtin_amdgcn_s_memrealtime() - t0 < limit_ticks)
+        __builtin_amdgcn_s_sleep(16);
+}
+
+static int reserve_cus()
+{
+    static const int v = [] { const char *e = getenv("GPX_RESERVE_CUS"); const int r = e ? atoi(e) : 32; return r < 0 ? 0 : (r > 128 ? 128 : r); }();
+    return v;
+}
+// the reservation starts with the first panel whose bulk launch has fewer 128 x 128 tiles than this (the tail of the factorisation,
+// where the chain, not the bulk, is the critical path)
+static long reserve_below_tiles()
+{
+    static const long v = [] { const char *e = getenv("GPX_RESERVE_TILES"); return e ? atol(e) : 3000L; }();
+    return v;
+}
+
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
                 hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork)
 {
@@ -746,6 +801,32 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         GPX_HIP(hipEventCreateWithFlags(&ev_first[p], hipEventDisableTiming));
     }
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
+    // CU reservation (above) for the tail of the factorisation: flag and placement counter live behind the status word; the
+    // blockers run on a stream of their own
+    const int nres = reserve_cus();
+    hipStream_t s_blk = nres ? stream_acquire(0) : nullptr;
+    int *stop_flag = info_dev + 1, *placed = info_dev + 2;
+    bool reserved = false, released = false;
+    hipEvent_t ev_blk = nullptr;
+    auto release_blockers = [&](hipStream_t on) {
+        if (reserved && !released) { hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, on, stop_flag, 1); released = true; }
+    };
+    // called where the main stream has just drained (it waits for panel p's chain): the blockers find an empty chip
+    auto reserve_now = [&]() -> int {
+        if (!s_blk || reserved) return 0;
+        GPX_HIP(hipEventCreateWithFlags(&ev_blk, hipEventDisableTiming));
+        GPX_HIP(hipMemsetAsync(stop_flag, 0, 2 * sizeof(int), s));
+        GPX_HIP(hipEventRecord(ev_blk, s));
+        GPX_HIP(hipStreamWaitEvent(s_blk, ev_blk, 0));
+        // time limit: generous multiple of the factorisation's expected duration (N^3/3 flop at 20 TFLOP/s), at least 50 ms
+        const double expect_s = (double)(nblk * TILE) * (double)(nblk * TILE) * (double)(nblk * TILE) / 3.0 / 20e12;
+        const unsigned long long limit = (unsigned long long)((0.05 + 4.0 * expect_s) * 1e8);
+        hipLaunchKernelGGL(cu_blocker_kernel, dim3((unsigned)nres), dim3(256), 0, s_blk, (const int *)stop_flag, placed, limit);
+        hipLaunchKernelGGL(wait_placed_kernel, dim3(1), dim3(1), 0, s, (const int *)placed, nres, 20000ull);   // <= 200 us
+        GPX_HIP(hipGetLastError());
+        reserved = true;
+        return 0;
+    };
     auto run = [&]() -> int {
         // Per outer panel p the main stream runs, in order:
         //   update of panel p+1's diagonal square (panel p's rows of that square are solved by then) -> event: the side
@@ -775,6 +856,13 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) break;
+            if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
+                GPX_TRY(reserve_now());
+                {   // the column solves stay off the reserved CUs (top_column)
+                    const char *e = getenv("GPX_TOP_BIG");
+                    for (int64_t q = p; q <= P; ++q) tops[q].big = e ? atoi(e) : 3;
+                }
+            }
             const int64_t K = (B1 - B0) * TILE;
             // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
             //     square before anything else so that the side stream starts early
@@ -802,6 +890,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 }
                 GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                        (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+                // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
+                if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1]));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
@@ -810,8 +900,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         return 0;
     };
     const int rc = run();
+    release_blockers(s);
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
+    if (s_blk) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s_blk); stream_release(s_blk, 0); }
+    if (ev_blk) (void)hipEventDestroy(ev_blk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
     for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }

@@ -300,6 +300,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
     }
 }
 
+// The 32/64-row tiles with the bulk kernel's register footprint (224 VGPRs): the same product, but the workgroup cannot settle on
+// the CUs reserved for the diagonal chain (chol.hip: 192 registers per SIMD are free there).  For the column solves that run
+// alongside the chain: they keep competing with the bulk for places, as before, instead of crowding the chain's CUs.
+template <int WM, int WN>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_fat_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int K,
+                                                                double alpha, double beta)
+{
+    constexpr int BTM = 32 * WM, BTN = 32 * WN;
+    __shared__ __attribute__((aligned(1024))) double smem[2 * (BTM + BTN) * 16];
+    asm volatile("v_mov_b32 v223, 0" ::: "v223");
+    gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, (int)blockIdx.x, (int)blockIdx.y, 0, K, alpha, beta, smem);
+}
+
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
 constexpr double SMALL_GRID_TILES = 192.0;
 
@@ -364,8 +377,14 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         const GemmBatch pa_ = {0, 0, 0, tri == GEMM_TRI_B_LOWER ? GEMM_TRI_B_LOWER_PAIRED : GEMM_TRI_B_UPPER_PAIRED};
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
                            (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
-    } else if (tiles >= SMALL_GRID_TILES || (big_tiles && !in_place)) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently
+    } else if (tiles >= SMALL_GRID_TILES || (big_tiles == 1 && !in_place) || big_tiles == 2) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently (2: also in place -- one 128-wide column tile per row block)
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
+    else if (N == TILE && big_tiles == 3) {   // the same 32/64-row tiles, kept off the CUs reserved for the chain (above)
+        if (tiles >= SMALL_GRID_TILES / 2)
+            hipLaunchKernelGGL((gemm_nt_f64_fat_kernel<2, 4>), dim3(1, (unsigned)(M / 64)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta);
+        else
+            hipLaunchKernelGGL((gemm_nt_f64_fat_kernel<1, 4>), dim3(1, (unsigned)(M / 32)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta);
+    }
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);
         else GPX_LAUNCH(1, 4);
