@@ -59,17 +59,72 @@ __device__ __forceinline__ double bperm_f64(double v, int byte_index)
 // In-kernel stamps of the leaf's phases: only in the builder-side probe build (tools/native/probe_leafk.hip defines the macro
 // and includes this file); the library build contains none of it.
 #ifdef GPX_LEAF_STAMPS
-__device__ unsigned long long g_leaf_stamps[16];
+__device__ unsigned long long g_leaf_stamps[48];
 #define LEAF_STAMP(i) do { if (threadIdx.x == 0) g_leaf_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 #define LEAF_STAMP_RT(i) do { if (threadIdx.x == 0) g_leaf_stamps[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define LEAF_ACC_BEGIN() unsigned long long acc_t_ = __builtin_amdgcn_s_memtime()
 #define LEAF_ACC(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) g_leaf_stamps[i] += n_ - acc_t_; acc_t_ = n_; } while (0)
+#define LEAF_ACC2(i, j) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) { g_leaf_stamps[i] += n_ - acc_t_; g_leaf_stamps[j] = n_ - acc_t_; } acc_t_ = n_; } while (0)
 #else
 #define LEAF_STAMP(i) do { } while (0)
 #define LEAF_STAMP_RT(i) do { } while (0)
 #define LEAF_ACC_BEGIN() do { } while (0)
 #define LEAF_ACC(i) do { } while (0)
+#define LEAF_ACC2(i, j) do { } while (0)
 #endif
+
+// One level of the recursive doubling of the factor's inverse: for every pair of adjacent S-block diagonal squares (inverses X11,
+// X22 already in place) X21 = -X22 (L21 X11).  The work is dealt so that every k loop has a compile-time trip count (the
+// fragment reads of a phase are then independent of its MFMAs and issue ahead of them): T = L21 X11 by block ROW (wave -> pair,
+// row; its S tasks j contract over k = j..S-1), X21 = -X22 T by block COLUMN (its S tasks i contract over k = 0..i) -- S(S+1)/2
+// block products per wave and phase for every wave.
+template <int S> __device__ __forceinline__ void leaf_inverse_level(double *X, int wave, int fr, int fq)
+{
+    const int p = (S == 4) ? 0 : (S == 2 ? wave >> 1 : wave);
+    const int idx = (S == 4) ? wave : (S == 2 ? wave & 1 : 0);
+    const int cb = 2 * S * p, rb = cb + S;
+    v4d res[S];
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = j; k < S; ++k) {
+            const double *Lk = &X[xblk(rb + idx, cb + k) + fr * 17 + fq];          // L21[idx][k]: A[row fr][4kk + fq]
+            const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];            // X11[k][j]:  B[4kk + fq][col fr]
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
+        }
+        res[j] = acc;
+    }
+    __syncthreads();   // all L21 reads are done before T lands in the same slots
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+        double *Tb = &X[xblk(rb + idx, cb + j)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[j][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k <= i; ++k) {
+            const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];            // X22[i][k]
+            const double *Tk = &X[xblk(rb + k, cb + idx) + fq * 17 + fr];          // T[k][idx]
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
+        }
+        res[i] = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < S; ++i) {
+        double *Xo = &X[xblk(rb + i, cb + idx)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[i][r];
+    }
+    __syncthreads();
+}
 
 // shared tail of the leaf variants: L -> global, then the inverse of the factor in place (recursive doubling over the 16-blocks)
 __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, double *diag_out, int *info, double *X, int *bad_sp)
@@ -102,71 +157,10 @@ __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, do
     __syncthreads();
 
     LEAF_STAMP(5);
-    // inverse, levels s = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
-    for (int s = 1; s <= 4; s <<= 1) {
-        const int npairs = 8 / (2 * s);
-        const int ntask = npairs * s * s;
-        v4d res[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s + i, cb = 2 * s * p;
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = j; k < s; ++k) {
-                    const double *Lk = &X[xblk(rb, cb + k) + fr * 17 + fq];                  // L21[i][k]: A[row fr][4kk + fq]
-                    const double *Xk = &X[xblk(cb + k, cb + j) + fq * 17 + fr];              // X11[k][j]: B[4kk + fq][col fr]
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lk[4 * kk], Xk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        __syncthreads();   // all L21 reads are done before T lands in the same slots
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Tb = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Tb[(fq + 4 * r) * 17 + fr] = res[q][r];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                const int rb = 2 * s * p + s, cb = 2 * s * p;
-                v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-                for (int k = 0; k <= i; ++k) {
-                    const double *Xa = &X[xblk(rb + i, rb + k) + fr * 17 + fq];
-                    const double *Tk = &X[xblk(rb + k, cb + j) + fq * 17 + fr];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[4 * kk], Tk[4 * kk * 17], acc, 0, 0, 0);
-                }
-                res[q] = acc;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int task = wave + 4 * q;
-            if (task < ntask) {
-                const int p = task / (s * s), ij = task - p * s * s, i = ij / s, j = ij - i * s;
-                double *Xo = &X[xblk(2 * s * p + s + i, 2 * s * p + j)];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Xo[(fq + 4 * r) * 17 + fr] = -res[q][r];
-            }
-        }
-        __syncthreads();
-    }
+    // inverse, levels S = 1, 2, 4 in place: X21 = -X22 (L21 X11); L21 is read from its own slot, which then takes T and X21
+    leaf_inverse_level<1>(X, wave, fr, fq);
+    leaf_inverse_level<2>(X, wave, fr, fq);
+    leaf_inverse_level<4>(X, wave, fr, fq);
     LEAF_STAMP(6);
     {
         const int r = t >> 4, c = t & 15;
@@ -349,7 +343,7 @@ template <int J> __device__ __forceinline__ void fmac_row_bcast(double &x, doubl
     asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(nw), "n"(J));
 }
 
-template <int J> __device__ __forceinline__ void elim_pivot(double (&d)[16], double &gi, double (&b)[7], double &piv, int c)
+template <int NB, int J> __device__ __forceinline__ void elim_pivot(double (&d)[16], double &gi, double (&b)[8], double &piv, int c)
 {
     const double dj = dpp_row_bcast<J>(d[J]);
     double r = __builtin_amdgcn_rcp(dj);
@@ -363,8 +357,73 @@ template <int J> __device__ __forceinline__ void elim_pivot(double (&d)[16], dou
     for (int i = J + 1; i < 16; ++i) fmac_row_bcast<J>(d[i], nw);   // the next pivot's row first
     fmac_row_bcast<J>(gi, nw);
 #pragma unroll
-    for (int q = 0; q < 7; ++q) fmac_row_bcast<J>(b[q], nw);
-    if constexpr (J + 1 < 16) elim_pivot<J + 1>(d, gi, b, piv, c);
+    for (int q = 0; q < 4 * NB; ++q) fmac_row_bcast<J>(b[q], nw);
+    if constexpr (J + 1 < 16) elim_pivot<NB, J + 1>(d, gi, b, piv, c);
+}
+
+// left-looking update of one 16 x 16 block of the current panel: A[ib][jb] - sum_{k < jb} L[ib][k] L[jb][k]^T, in accumulator
+// layout (lane (fq, fr): rows fq + 4 r, column fr), fragments of step k + 1 read while the MFMAs of step k run
+__device__ __forceinline__ v4d leaf_block_update(const double *X, int ib, int jb, int fr, int fq)
+{
+    const double *Cb = &X[xblk(ib, jb)];
+    v4d acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = Cb[(fq + 4 * r) * 17 + fr];
+    if (jb == 0) return acc;
+    double la[2][4], lb[2][4];
+    const int rowa = xblk(ib, 0) + fr * 17 + fq, rowb = xblk(jb, 0) + fr * 17 + fq;   // blocks (i, k) of a row are XB apart
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { la[0][kk] = X[rowa + 4 * kk]; lb[0][kk] = X[rowb + 4 * kk]; }
+    for (int k = 0; k < jb; k += 2) {
+        if (k + 1 < jb) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { la[1][kk] = X[rowa + (k + 1) * XB + 4 * kk]; lb[1][kk] = X[rowb + (k + 1) * XB + 4 * kk]; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[0][kk], lb[0][kk], acc, 0, 0, 0);
+        if (k + 1 < jb) {
+            if (k + 2 < jb) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) { la[0][kk] = X[rowa + (k + 2) * XB + 4 * kk]; lb[0][kk] = X[rowb + (k + 2) * XB + 4 * kk]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[1][kk], lb[1][kk], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+// elimination of one panel: the group's copy of the diagonal block d, its row gi of the appended identity, and the rows b of
+// the wave's NB blocks below (accumulator layout = elimination layout: group fq holds rows fq + 4 r of a block); stores
+// L_ib, inv(L_d) (diagonal 16-block of dinv) and -- the first group of every wave -- a quarter of L_d
+template <int NB>
+__device__ __forceinline__ void leaf_panel_eliminate(double *X, double *dinv, int jb, const v4d (&acc)[2], const int (&ibs)[2], int wave, int fq,
+                                                     int g, int c, int col_offset, int *bad_sp)
+{
+    double *Db = &X[xblk(jb, jb)];
+    double d[16], b[8], gi, piv = 1.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = Db[(i >= c) ? i * 17 + c : c * 17 + i];     // symmetric image from the lower triangle
+    gi = (c == g) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) b[q] = acc[q >> 2][q & 3];
+    elim_pivot<NB, 0>(d, gi, b, piv, c);
+    const double sc = fast_rsqrt(piv);           // lane c: 1 / L_cc
+    // a non-positive (or NaN) pivot: first such column of the first such panel
+    const unsigned long long badm = __builtin_amdgcn_ballot_w64(!(piv > 0.0)) & 0xffffull;
+    if (threadIdx.x == 0 && badm && *bad_sp == 0) *bad_sp = col_offset + 16 * jb + __builtin_ctzll(badm) + 1;
+    dinv[(16 * jb + c) * TILE + 16 * jb + g] = gi * sc;   // inv(L_d)[c][g]; exactly zero for c < g
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        double *Ob = &X[xblk(ibs[q], jb)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ob[(fq + 4 * r) * 17 + c] = b[4 * q + r] * sc;
+    }
+    if (fq == 0) {   // the first group of every wave stores the rows i = wave (mod 4) of the diagonal block
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if ((i & 3) == wave) Db[i * 17 + c] = (i >= c) ? d[i] * sc : 0.0;
+    }
 }
 
 __device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
@@ -395,75 +454,33 @@ __device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv,
     LEAF_STAMP(1);
     LEAF_ACC_BEGIN();
 
+    // Left-looking over the eight 16-column panels.  Per panel: every wave brings its (at most two) blocks below the diagonal
+    // up to date in registers, wave 3 -- which owns the fewest of them -- the diagonal block as well, handing it over through
+    // LDS; then the elimination runs on the accumulators as they stand.  A block of the trailing matrix is read once and
+    // written once; two barriers per panel.
 #pragma unroll 1
     for (int jb = 0; jb < 8; ++jb) {
-        {
+        const int nb = 7 - jb;                                   // blocks below the diagonal
+        const int nbw = (wave < nb ? 1 : 0) + (wave + 4 < nb ? 1 : 0);
+        const int ibs[2] = {jb + 1 + wave, jb + 5 + wave};
+        v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
+        if (jb > 0 && wave == 3) {
+            const v4d dacc = leaf_block_update(X, jb, jb, fr, fq);
             double *Db = &X[xblk(jb, jb)];
-            double d[16], b[7], gi, piv = 1.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = Db[(i >= c) ? i * 17 + c : c * 17 + i];     // symmetric image from the lower triangle
-            gi = (c == g) ? 1.0 : 0.0;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int ib = jb + 1 + q;
-                b[q] = (ib < 8) ? X[xblk(ib < 8 ? ib : 7, jb) + g * 17 + c] : 0.0;
-            }
-            elim_pivot<0>(d, gi, b, piv, c);
-            const double sc = fast_rsqrt(piv);           // lane c: 1 / L_cc
-            // a non-positive (or NaN) pivot: first such column of the first such panel
-            const unsigned long long badm = __builtin_amdgcn_ballot_w64(!(piv > 0.0)) & 0xffffull;
-            if (t == 0 && badm && bad_s == 0) bad_s = col_offset + 16 * jb + __builtin_ctzll(badm) + 1;
-            dinv[(16 * jb + c) * TILE + 16 * jb + g] = gi * sc;   // inv(L_d)[c][g]; exactly zero for c < g
-#pragma unroll
-            for (int q = 0; q < 7; ++q) {
-                const int ib = jb + 1 + q;
-                if (ib < 8) X[xblk(ib, jb) + g * 17 + c] = b[q] * sc;
-            }
-            if (fq == 0) {   // the first group of every wave stores the rows i = wave (mod 4) of the diagonal block
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if ((i & 3) == wave) Db[i * 17 + c] = (i >= c) ? d[i] * sc : 0.0;
-            }
+            for (int r = 0; r < 4; ++r) Db[(fq + 4 * r) * 17 + fr] = dacc[r];
         }
+        if (nbw > 0) acc[0] = leaf_block_update(X, ibs[0], jb, fr, fq);
+        if (nbw > 1) acc[1] = leaf_block_update(X, ibs[1], jb, fr, fq);
+        LEAF_ACC2(3, 16 + jb);
+        if (jb > 0) __syncthreads();
+        LEAF_ACC2(3, 24 + jb);
+        if (nbw == 2) leaf_panel_eliminate<2>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        else if (nbw == 1) leaf_panel_eliminate<1>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        else leaf_panel_eliminate<0>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        LEAF_ACC2(2, 32 + jb);
         __syncthreads();
-        LEAF_ACC(2);
-        // ---- trailing update: A[ib][kb] -= L[ib][jb] L[kb][jb]^T, jb < kb <= ib; two tasks in flight per wave ----
-        {
-            const int nb = 7 - jb;
-            const int ntask = nb * (nb + 1) / 2;
-            for (int task0 = wave; task0 < ntask; task0 += 8) {
-                v4d acc[2];
-                double *Cb[2];
-                double la[2][4], lb[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int task = task0 + 4 * u;
-                    const int tk = task < ntask ? task : task0;
-                    int ii = 0;
-                    while ((ii + 1) * (ii + 2) / 2 <= tk) ++ii;           // row within the trailing triangle
-                    const int kk0 = tk - ii * (ii + 1) / 2;
-                    const int ib = jb + 1 + ii, kb = jb + 1 + kk0;
-                    Cb[u] = &X[xblk(ib, kb)];
-                    const double *La = &X[xblk(ib, jb) + fr * 17 + fq];
-                    const double *Lb = &X[xblk(kb, jb) + fr * 17 + fq];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[u][r] = Cb[u][(fq + 4 * r) * 17 + fr];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) { la[u][kk] = -La[4 * kk]; lb[u][kk] = Lb[4 * kk]; }
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[u][kk], lb[u][kk], acc[u], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (u == 0 || task0 + 4 < ntask)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) Cb[u][(fq + 4 * r) * 17 + fr] = acc[u][r];
-            }
-        }
-        __syncthreads();
-        LEAF_ACC(3);
+        LEAF_ACC2(2, 40 + jb);
     }
     leaf_finish(A, ld, dinv, diag_out, info, X, bad_sp);
 #undef bad_s
@@ -489,12 +506,27 @@ static int leaf_variant()
     return v;
 }
 
+// exclusive: the launch asks for 52 KB of dynamic LDS on top of the kernel's 78 KB, so that no workgroup of any GEMM variant
+// (>= 32 KB) can join it on its CU -- next to a bulk wave on every SIMD the leaf runs 3x slower.  Only where an empty CU is at
+// hand: the first leaf of a panel (the main stream has just drained) and every leaf while CUs are reserved for the chain.
+static int leaf_exclusive_enabled()
+{
+    static const int v = [] {
+        const char *e = getenv("GPX_LEAF_EXCL");
+        const int on = e ? atoi(e) : 1;
+        if (on) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(potrf_trtri128_elim_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 52 * 1024);
+        return on;
+    }();
+    return v;
+}
+
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
-                      hipStream_t s, Profiler *prof)
+                      hipStream_t s, Profiler *prof, int exclusive)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
     if (leaf_variant())
-        hipLaunchKernelGGL(potrf_trtri128_elim_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset, leaf_prio());
+        hipLaunchKernelGGL(potrf_trtri128_elim_kernel, dim3(1), dim3(256), (exclusive && leaf_exclusive_enabled()) ? 52 * 1024 : 0, s, A, (long)ld, dinv,
+                           diag_out, info_dev, col_offset, leaf_prio());
     else
         hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
     GPX_HIP(hipGetLastError());
@@ -504,7 +536,7 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 extern "C" int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                                   void *stream)
 {
-    return launch_potrf_leaf(A, ld, dinv, diag_out, info_dev, col_offset, (hipStream_t)stream, nullptr);
+    return launch_potrf_leaf(A, ld, dinv, diag_out, info_dev, col_offset, (hipStream_t)stream, nullptr, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -580,7 +612,7 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
     if (nb <= 0) return 0;
     if (nb == 1)
         return launch_potrf_leaf(L + (b0 * TILE) * ld + b0 * TILE, ld, Dinv + b0 * (int64_t)TILE * TILE,
-                                 diagL + b0 * TILE, info_dev, (int)(b0 * TILE), s, prof);
+                                 diagL + b0 * TILE, info_dev, (int)(b0 * TILE), s, prof, 0);
     const int64_t h = split_point(nb), bm = b0 + h;
     GPX_TRY(chol_rec(L, ld, b0, bm, Dinv, diagL, info_dev, s, prof));
     // A21 <- A21 L11^-T : rows [bm,b1), triangle [b0,bm)
@@ -633,11 +665,12 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
 }
 
 static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
-                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, const TopPipe *top = nullptr)
+                             double *diagL, int *info_dev, hipStream_t s, Profiler *prof, const TopPipe *top = nullptr, int excl = 0)
 {
+    // excl: 1 = the step j == B0 runs its leaf exclusively (launch_potrf_leaf), 2 = every step
     for (int64_t j = j0; j < j1; ++j) {
         GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE, info_dev,
-                                  (int)(j * TILE), s, prof));
+                                  (int)(j * TILE), s, prof, excl == 2 || (excl == 1 && j == B0)));
         const int64_t rows_below = B1 - (j + 1);
         if (rows_below > 0) {
             double *Z = L + ((j + 1) * TILE) * ld + j * TILE;                 // rows below the diagonal block, column block j
@@ -645,6 +678,9 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
             // right-looking inside the square.  (Left-looking -- only the next block column updated per step, <= 28 workgroups
             // with K up to 896 -- was measured: a step then takes one workgroup's 24 us for a 32 x 128 x 896 tile instead of
             // spreading K = 128 tiles over the chip; the chain of an idle chip went from 480 to 577 us per panel.)
+            // Also measured: only the next block column updated on the chain's stream and the remaining columns on a second
+            // stream underneath the next leaf (joined one step later) -- two more cross-stream event edges per step cost more than
+            // the shorter launches gain (fit 29.7 -> 33.2 ms).
             GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
                                    rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
         }
@@ -736,14 +772,14 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
 // retiring bulk workgroup's place -- equal-length tiles retire in bursts -- and then runs 3x (next to one bulk wave per SIMD)
 // to 10x (next to two) slower than alone; kernels small enough to be placed at once (<= 64 VGPRs, <= 16 KB of LDS) pay the
 // 10x.  Neither stream priorities nor s_setprio change that.  What does: a few CUs that the bulk cannot enter.  A "blocker"
-// workgroup of four sleeping waves that each hold 320 VGPRs leaves 192 registers per SIMD: no bulk wave (224) fits there, the
-// chain's kernels (leaf 144, 32/64-row GEMM tiles 80-122 VGPRs) do, and the whole LDS stays free.  R blockers launched on an
+// workgroup of four sleeping waves that each hold 312 VGPRs leaves 200 registers per SIMD: no bulk wave (224) fits there, the
+// chain's kernels (leaf 200, 32/64-row GEMM tiles 80-122 VGPRs) do, and the whole LDS stays free.  R blockers launched on an
 // idle chip take R distinct CUs (two cannot share one), dealt round-robin over the XCDs; they leave when the flag is set (after
 // the last bulk launch of the factorisation) or, whatever happens to the host, when their time limit expires.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cu_blocker_kernel(const int *stop, int *placed, unsigned long long limit_ticks)
 {
-    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a63, 0" ::: "v255", "a63");   // 256 VGPRs + 64 AGPRs: 320 registers per wave
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a55, 0" ::: "v255", "a55");   // 256 VGPRs + 56 AGPRs: 312 registers per wave
     if (threadIdx.x == 0) __hip_atomic_fetch_add(placed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 64) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
@@ -849,7 +885,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued now, it runs
         // underneath the first panel's chain
         if (after_fork) GPX_TRY((*after_fork)());
-        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0]));
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 1));
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
@@ -875,7 +911,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, 1));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
@@ -893,7 +929,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1]));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved && !released) ? 2 : 0));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }

@@ -162,7 +162,7 @@ struct GemmBatch { int nq; long sp, sq; int tri; };
 int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
                            GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
-                      hipStream_t s, Profiler *prof);
+                      hipStream_t s, Profiler *prof, int exclusive = 0);
 
 // recursive blocked algorithms (chol.hip)
 // after_fork: main-stream work that only the panels after the first depend on (called once, right after the first panel's

@@ -25,6 +25,16 @@ static void report(const char *what, const std::vector<std::vector<unsigned long
     }
     for (int i = 0; i < 7; ++i) { std::sort(col[i].begin(), col[i].end()); printf("   %-15s %8.0f   (min %8.0f max %8.0f)\n", names[i], col[i][col[i].size() / 2], col[i].front(), col[i].back()); }
     std::sort(col[7].begin(), col[7].end());
+    for (int base = 16; base < 48; base += 8) {
+        printf("   per panel %s:", base == 16 ? "U (wave 0)   " : base == 24 ? "U barrier    " : base == 32 ? "E (wave 0)   " : "E barrier    ");
+        for (int jb = 0; jb < 8; ++jb) {
+            std::vector<double> v;
+            for (auto &s : all) v.push_back((double)s[base + jb]);
+            std::sort(v.begin(), v.end());
+            printf(" %6.0f", v[v.size() / 2]);
+        }
+        printf("\n");
+    }
     printf("   clock %.2f GHz (median), leaf %.1f us at that clock\n", col[7][col[7].size() / 2], col[6][col[6].size() / 2] / col[7][col[7].size() / 2] * 1e-3);
 }
 
@@ -61,9 +71,9 @@ int main()
                     if (gpx_dev_gemm_nt(P, K, P, K, C, n, n, n, K, -1.0, 1.0, 1, bulk)) { printf("gemm: %s\n", gpx_last_error()); return 1; }
             for (int i = 0; i < NL; ++i) {
                 if (launch_potrf_leaf(A + (size_t)i * 128 * 128, 128, dinv, diag, info, 0, side, nullptr)) return 1;
-                std::vector<unsigned long long> st(16);
+                std::vector<unsigned long long> st(48);
                 CK(hipStreamSynchronize(side));
-                CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_leaf_stamps), sizeof(unsigned long long) * 16));
+                CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_leaf_stamps), sizeof(unsigned long long) * 48));
                 if (rep) all.push_back(st);
             }
             CK(hipDeviceSynchronize());
