@@ -3,6 +3,10 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
 
+`--gpus N` with N > 1 may be started either under torch.distributed.run (one rank per GPU; RANK / WORLD_SIZE in the
+environment) or as a plain script: it then launches torch.distributed.run itself as a child process and forwards rank 0's line.
+`--gpus 1 --workload c4` is the one-GPU point of the C4 scaling curve (same workload as the N > 1 lines).
+
 One "step" = one pass of the hot path over one batch of synthetic input:
 fit (Gram + vt I -> blocked fp64 Cholesky -> alpha) followed by estimate_many on M = N queries.
 Inputs (x, t, xs) are resident in HBM before the timed region; outputs stay on the device.
@@ -30,6 +34,51 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "scikit-gpuppy_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+
+
+def requested_gpus(argv):
+    """--gpus N from a raw argument list (no other parsing: runs before any heavy import)"""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def self_launch(argv, ngpus, target=None, port=None):
+    """`bench.py --gpus N` (N > 1) started as a plain script: run one rank per GPU as a FRESH child process
+    (python -m torch.distributed.run ... bench.py <the same arguments>), pass rank 0's JSON line on to stdout and
+    return the child's exit code.  This process never touches the GPU and nothing is exec'ed over a process that did."""
+    import subprocess
+    target = target or os.environ.get("GPX_BENCH_LAUNCH_TARGET") or os.path.abspath(__file__)
+    port = port or os.environ.get("GPX_BENCH_MASTER_PORT", "29511")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), target] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    last = None
+    for line in proc.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and line.endswith("}"):
+            last = line                      # the contract: ONE JSON line on stdout (rank 0's)
+        elif line:
+            sys.stderr.write(line + "\n")   # anything else a rank printed
+    rc = proc.wait()
+    if last is not None:
+        print(last)
+        sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: the %d-rank child run exited with code %d\n" % (ngpus, rc))
+    return rc if rc != 0 or last is not None else 1
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and not os.environ.get("GPX_BENCH_SHARDED"):
+    _n = requested_gpus(sys.argv[1:])
+    if _n > 1:
+        raise SystemExit(self_launch(sys.argv[1:], _n))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  (before libgpx: one shared HIP runtime)
@@ -109,7 +158,7 @@ def cpu_baseline(N, d, M, budget_s=300.0):
     t2 = time.perf_counter()
     return {"N": Ns, "M": Ms, "fit_s": t1 - t0, "predict_s": t2 - t1, "probe_2048_s": probe, "probe_4096_s": probes[4096],
             "probe_exponent": float(p_exp), "mean": mean, "var": var,
-            "inputs": (x, t, xs, theta)}
+            "inputs": (x, t, xs, theta), "oracle_gp": gp}
 
 
 def python_api_section(N, d, M, reps=2):
@@ -177,6 +226,94 @@ def propagate_section(lib, _gpx, vp, xd, td, th, N, d):
             res[name] = {"launches": n_.value, "avg_ms": per, "kinv_bytes": nbytes,
                          "hbm_GBs": nbytes / (per * 1e-3) / 1e9, "frac_of_8TBs": nbytes / (per * 1e-3) / 1e9 / HBM_PEAK_GBS}
     lib.gpx_free(h)
+    return res
+
+
+def likelihood_section(N, d):
+    """"next" row f1 at the benchmark size, outside the timed region: one evaluation of the hyper-parameter likelihood and of its
+    gradient at a new theta through the Python classes (what one L-BFGS-B iteration of GaussianCovariance.ml_estimate costs):
+    fit + log det, then K^-1 and the fused gradient pass on the same device model."""
+    import skgpuppy_amd as sk
+    x, t, _xs, theta = recipe(N, d, 16)
+    tc = t - t.mean()
+    cov = sk.GaussianCovariance()
+    best = None
+    for rep in range(3):
+        th = theta + 0.01 * (rep + 1)
+        a = time.perf_counter()
+        val = cov._negativeloglikelihood(x, tc, th)
+        b = time.perf_counter()
+        g = cov._d_nll_d_theta(x, tc, th)
+        c = time.perf_counter()
+        if rep and (best is None or c - a < best[0]):
+            best = (c - a, b - a, c - b, val, float(np.abs(g).max()))
+    cached = getattr(cov, "_ml_cache", None)
+    if cached is not None:
+        cached[1].close()
+    return {"workload": "N=%d d=%d: _negativeloglikelihood + _d_nll_d_theta at a new theta (host arrays in)" % (N, d),
+            "nll_ms": best[1] * 1e3, "gradient_ms": best[2] * 1e3, "iteration_ms": best[0] * 1e3, "nll": best[3], "max_abs_gradient": best[4],
+            "algorithmic_flops": N ** 3 / 3.0 + 2.0 * N ** 3 / 3.0,       # Cholesky + K^-1 from the factor
+            "tflops": (N ** 3 / 3.0 + 2.0 * N ** 3 / 3.0) / best[0] / 1e12}
+
+
+def spgp_section(n=262144, m=2048, d=8, queries=16384, reps=2):
+    """"next" row f3 at BASELINE config 5 (Snelson SPGP, M = 2048 pseudo-inputs, N = 262144, d = 8), outside the timed region:
+    low-rank fit, estimate_many, Snelson's likelihood and its analytic gradient on one GPU (the same figures tools/bench_spgp.py prints)."""
+    import skgpuppy_amd as sk
+    rng = np.random.RandomState(20240 + n + d)
+    x = rng.uniform(0, 10, (n, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(n)
+    xs = rng.uniform(0, 10, (queries, d))
+    xb = x[rng.choice(n, m, replace=False)].copy()
+    theta = np.concatenate([np.log(np.array([2.0, 0.01] + [0.04] * d)), xb.ravel()])
+    cov = sk.SPGPCovariance(m)
+    best = None
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        gp = sk.GaussianProcess(x, t, cov, theta)
+        t1 = time.perf_counter()
+        mu, _var = gp.estimate_many(xs)
+        t2 = time.perf_counter()
+        val = gp._dev().nll()
+        t3 = time.perf_counter()
+        g = gp._dev().nll_grad()
+        t4 = time.perf_counter()
+        gp._dev().close()
+        cur = (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+        if r:
+            best = cur if best is None else tuple(min(a_, b_) for a_, b_ in zip(best, cur))
+    flops_fit = 2.0 * n * m * m + 2.0 * m ** 3 / 3.0          # TRSM + lower-only W^T W + two Cholesky
+    return {"workload": "C5: SPGP N=%d M=%d d=%d, %d queries" % (n, m, d, queries), "fit_ms": best[0] * 1e3, "estimate_many_ms": best[1] * 1e3,
+            "snelson_nll_ms": best[2] * 1e3, "analytic_gradient_ms": best[3] * 1e3, "train_pts_per_s": n / best[0],
+            "fit_tflops_algorithmic": flops_fit / best[0] / 1e12, "fit_frac_of_peak": flops_fit / best[0] / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "nll": val, "gradient_finite": bool(np.all(np.isfinite(g))),
+            "mean_abs_residual": float(np.abs(mu - np.sin(0.3 * xs.sum(1))).mean())}
+
+
+def propagate_parity(cb, d):
+    """Config C3's second half against the oracle at the benchmark size: propagate_GA (Approx and Exact, u = 5 1_d, Sigma = 0.01 I)
+    on a GPU fit of the oracle's inputs against oracle.approx_propagate / exact_propagate on the oracle's own K^-1 (serial C
+    loops, UncertaintyPropagation2.pyx order).  SURVEY 8a tolerances: mean 1e-9 absolute, variances 1e-8 v absolute."""
+    import skgpuppy_amd as sk
+    from oracle import oracle as orc
+    xo, to_, _xso, tho = cb["inputs"]
+    og = cb["oracle_gp"]
+    u, S = np.full(d, 5.0), 0.01 * np.eye(d)
+    t0 = time.perf_counter()
+    oa = orc.approx_propagate(og, u, S)
+    t1 = time.perf_counter()
+    oe = orc.exact_propagate(og, u, S)
+    t2 = time.perf_counter()
+    gp = sk.GaussianProcess(xo, to_, sk.GaussianCovariance(), tho.copy())
+    ga = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+    ge = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
+    gp._dev().close()
+    v_ = float(np.exp(tho[0]))
+    res = {"u": "5 * 1_d", "Sigma": "0.01 I", "oracle_approx_s": t1 - t0, "oracle_exact_s": t2 - t1,
+           "approx": {"gpu": [float(ga[0]), float(ga[1])], "oracle": [float(oa[0]), float(oa[1])]},
+           "exact": {"gpu": [float(ge[0]), float(ge[1])], "oracle": [float(oe[0]), float(oe[1])]},
+           "tolerance": "mean 1e-9 abs, variance 1e-8 v abs"}
+    res["ok"] = bool(abs(ga[0] - oa[0]) < 1e-9 and abs(ga[1] - oa[1]) < 1e-8 * v_ and abs(ge[0] - oe[0]) < 1e-9 and abs(ge[1] - oe[1]) < 1e-8 * v_)
     return res
 
 
@@ -281,7 +418,7 @@ def run_single(args):
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",     # the workload (total work) is fixed; N > 1 lines shard the SAME kind of step at config C4
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
@@ -320,6 +457,12 @@ def run_single(args):
         out["propagate"] = propagate_section(lib, _gpx, vp, xd, td, th, N, d)
     if not args.no_python_api:
         out["python_api"], mean_py, var_py = python_api_section(N, d, M)
+    if not args.no_extras:
+        out["likelihood_f1"] = likelihood_section(N, d)
+        if (args.workload or "c3") == "c3":
+            _gpx.lib.gpx_pool_trim()
+            out["spgp_c5_f3"] = spgp_section()
+            _gpx.lib.gpx_pool_trim()
     if not args.no_cpu:
         cb = cpu_baseline(N, d, M, budget_s=args.cpu_budget)
         Ns, Ms, tf, tp = cb["N"], cb["M"], cb["fit_s"], cb["predict_s"]
@@ -359,6 +502,12 @@ def run_single(args):
         if not ok:
             print(json.dumps(out))
             raise SystemExit("bench.py: GPU outputs differ from the oracle beyond tolerance: %r" % (out["parity_vs_oracle"],))
+        if not args.no_propagate:
+            pp = propagate_parity(cb, d)
+            out["parity_vs_oracle"]["propagate_GA"] = pp
+            if not pp["ok"]:
+                print(json.dumps(out))
+                raise SystemExit("bench.py: propagate_GA differs from the oracle beyond tolerance: %r" % (pp,))
     print(json.dumps(out))
 
 
@@ -371,12 +520,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg (and the parity check against it)")
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="seconds the CPU baseline may take (full workload if it fits)")
     ap.add_argument("--no-python-api", action="store_true", help="skip the second figure through the Python classes")
-    ap.add_argument("--no-propagate", action="store_true", help="skip the (untimed) propagate_GA section")
+    ap.add_argument("--no-propagate", action="store_true", help="skip the (untimed) propagate_GA section and its parity check against the oracle")
+    ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) likelihood (f1) and SPGP config-5 (f3) figures")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit("bench.py --gpus %d needs one rank per GPU: launch it as\n  python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("GPX_BENCH_SHARDED"):
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))    # (imported and called as main(): the module-level launcher did not run)
     rehearsal = bool(os.environ.get("GPX_BENCH_SHARDED"))    # diagnostic: the sharded code path with ONE rank (world size 1)
     if args.gpus != world and not rehearsal:
         raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))

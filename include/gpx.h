@@ -48,7 +48,9 @@ typedef struct gpx_handle gpx_handle;
 int         gpx_abi_version(void);
 const char *gpx_last_error(void);                 /* thread-local text of the last failure */
 int         gpx_device_count(void);               /* number of visible HIP devices (0 if none) */
-int         gpx_set_device(int device);           /* device used by subsequently created handles */
+int         gpx_set_device(int device);           /* device used by handles created afterwards BY THE CALLING THREAD: the choice is
+                                                     per host thread (thread-local, default device 0) -- a worker thread that never
+                                                     calls it creates its handles on device 0, whatever another thread selected */
 int         gpx_pool_trim(void);                  /* release the device buffers cached by the library's allocator */
 
 /* ---- a1/a2: GaussianCovariance.cov_matrix_ij / cov_matrix  (skgpuppy/Covariance.py:461-483) ----
@@ -114,6 +116,12 @@ int gpx_propagate_approx(gpx_handle *h, const double *u, const double *Sigma,
  * 4 + 2 d doubles) and finish on the host: skgpuppy_amd.distributed.combine_approx_partials. */
 int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1,
                               double *partial_out);
+
+/* Right-hand-side-sharded form (multi-GPU host, no K^-1 on any rank): the share of the same 4 + 2 d sums that the vectors
+ * k0 <= k < k1 of [C, J_1..J_d] carry (0: beta.C, beta.tr, C.KinvC, KinvC.tr; k >= 1: J_k.KinvJ_k, beta.J_k), K^-1 v through the
+ * two-sweep triangular solver on the rank's copy of the factor; all other entries zero.  One all-reduce, then
+ * skgpuppy_amd.distributed.combine_approx_partials as above. */
+int gpx_propagate_approx_rhs(gpx_handle *h, const double *u, const double *Sigma, int k0, int k1, double *partial_out);
 
 /* ---- a13: UncertaintyPropagationApprox._get_variance_dv_h for every h in [0,d)
  * (skgpuppy/UncertaintyPropagation.py:564-630, UncertaintyPropagation2.pyx:340-380) ---- */

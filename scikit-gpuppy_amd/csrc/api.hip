@@ -924,6 +924,62 @@ extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const d
     return 0;
 }
 
+// Right-hand-side-sharded form of the Approx propagation for the multi-GPU host: the share of the 4 + 2 d sums (same order as
+// gpx_propagate_approx_rows) that the vectors k0 <= k < k1 of [C, J_1 .. J_d] contribute -- vector 0 carries beta.C, beta.tr,
+// C.KinvC, KinvC.tr; vector k >= 1 carries J_k.KinvJ_k and beta.J_k -- with K^-1 v through the two-sweep triangular solver on the
+// rank's copy of the factor.  No K^-1 is ever materialised (34 GB per rank at N = 65536); the other entries come back zero, the
+// ranks add their vectors in one all-reduce.  (The sweeps are bound by the bytes of the factor, not by the number of vectors:
+// the split saves memory, not time.)
+extern "C" int gpx_propagate_approx_rhs(gpx_handle *h, const double *u, const double *Sigma, int k0, int k1, double *partial_out)
+{
+    CHECK_H(h);
+    if (!u || !Sigma || !partial_out || k0 < 0 || k1 < k0 || k1 > h->d + 1) {
+        gpx_set_error("gpx_propagate_approx_rhs: bad arguments (vectors [%d, %d) of %d)", k0, k1, h->d + 1);
+        return GPX_ERR_BAD_ARG;
+    }
+    const int d = h->d;
+    const int64_t np = h->npad;
+    hipStream_t s = h->stream;
+    GPX_TRY(ensure_prop_buffers(h));
+    h->have_u = false;   // KV is about to hold some rows only
+    double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
+    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    GPX_HIP(hipMemcpyAsync(udev_ptr(h), uh, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipMemcpyAsync(sigma_ptr(h), Sh, sizeof(double) * d * d, hipMemcpyHostToDevice, s));
+    GPX_HIP(hipStreamSynchronize(s));   // stack buffers
+    const int npair = 4 + 2 * d;
+    double o[4 + 2 * GPX_MAX_D];
+    for (int i = 0; i < npair; ++i) o[i] = 0.0;
+    if (k1 > k0) {
+        GPX_TRY(launch_approx_build(h->x, h->n, np, d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
+        double *tr = aux_ptr(h);
+        GPX_TRY(launch_trace(h->x, h->n, np, d, udev_ptr(h), h->wdev, sigma_ptr(h), cplain_ptr(h), tr, s));
+        for (int c0 = k0; c0 < k1; c0 += 32)
+            GPX_TRY(h->tri.solve(h->V + (int64_t)c0 * np, np, std::min(32, k1 - c0), nullptr, h->KV + (int64_t)c0 * np, s, &h->prof));
+        std::vector<std::pair<const double *, const double *>> pr;
+        std::vector<int> slot;
+        if (k0 == 0) {
+            const double *C = h->V, *KC = h->KV;
+            pr.push_back({h->alpha, C});  slot.push_back(0);
+            pr.push_back({h->alpha, tr}); slot.push_back(1);
+            pr.push_back({C, KC});        slot.push_back(2);
+            pr.push_back({KC, tr});       slot.push_back(3);
+        }
+        for (int k = std::max(k0, 1); k < k1; ++k) {
+            pr.push_back({h->V + (int64_t)k * np, h->KV + (int64_t)k * np}); slot.push_back(4 + 2 * (k - 1));
+            pr.push_back({h->alpha, h->V + (int64_t)k * np});               slot.push_back(5 + 2 * (k - 1));
+        }
+        GPX_TRY(launch_dot_pairs(pr, np, out_ptr(h), s));
+        double tmp[4 + 2 * GPX_MAX_D];
+        GPX_HIP(hipMemcpyAsync(tmp, out_ptr(h), sizeof(double) * pr.size(), hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < pr.size(); ++i) o[slot[i]] = tmp[i];
+    }
+    GPX_HIP(hipMemcpy(partial_out, o, sizeof(double) * npair, hipMemcpyDefault));
+    return 0;
+}
+
 extern "C" int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out)
 {
     CHECK_H(h);

@@ -590,14 +590,21 @@ static int trtri_upper_rec(double *Z, int64_t ldz, const double *L, int64_t ldl,
     return trtri_upper_rec(Z, ldz, L, ldl, Dinv, cm, c1, s, prof);
 }
 
+// Z (npad x npad) <- L^-T (upper triangular, row-major): identity, then the structured recursion above
+int build_linv_t(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, hipStream_t s, Profiler *prof)
+{
+    const int64_t npad = nblk * TILE;
+    GPX_TRY(launch_set_identity(Z, npad, npad, s));
+    return trtri_upper_rec(Z, npad, L, ld, Dinv, 0, nblk, s, prof);
+}
+
 // Kinv = L^-T L^-1 from the factor: Z (scratch, npad x npad) = L^-T, then Kinv[i,j] = sum_{k >= i} Z[i,k] Z[j,k] for the
 // lower triangle in row strips of 1024 (the k range of a strip starts at its first row), mirrored to the upper one.
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof)
 {
     const int64_t npad = nblk * TILE;
-    GPX_TRY(launch_set_identity(Z, npad, npad, s));
-    GPX_TRY(trtri_upper_rec(Z, npad, L, ld, Dinv, 0, nblk, s, prof));
+    GPX_TRY(build_linv_t(L, ld, nblk, Dinv, Z, s, prof));
     // ONE lower-only launch whose tile (by, bx) contracts over k >= 128 by only (Z is upper triangular): N^3/3 flop with
     // tiles of length 128 .. N dealt longest-first to whichever workgroup slot frees up (row strips of 1024 with a common
     // k range per strip ran at 49 TFLOP/s: the first strips have few tiles, the last ones short k)

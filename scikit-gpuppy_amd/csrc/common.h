@@ -185,6 +185,8 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
                           hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
+// Z [npad, npad] <- L^-T (upper triangular, row-major) from the factor and its inverted diagonal blocks
+int build_linv_t(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
 int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
                           double *mean, double *var, hipStream_t s, Profiler *prof);

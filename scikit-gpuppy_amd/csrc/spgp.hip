@@ -205,15 +205,17 @@ static int spgp_chol_km(gpx_spgp *h, double jitter, double *L, double *Dinv, dou
     return 0;
 }
 
-// out <- inv(L) (lower, row-major): inv(L)^T by the structured recursion of the dense path, then its transpose.
-// scrA is used; out must not be scrA (it also receives, first, the product inv(L)^T inv(L) the helper forms).
-static int spgp_linv(gpx_spgp *h, const double *L, const double *Dinv, double *out)
+// out <- inv(L) (lower, row-major), linv_t <- inv(L)^T (upper): the structured triangular inversion of the dense path
+// (build_linv_t), then its transpose.  out and linv_t must differ; callers that go on using inv(L)^T pass the buffer they
+// want it in (default: scrA).
+static int spgp_linv(gpx_spgp *h, const double *L, const double *Dinv, double *out, double *linv_t = nullptr)
 {
     hipStream_t s = h->stream;
     const int64_t mp = h->mpad;
-    GPX_TRY(build_kinv_from_factor(L, mp, h->mblk, Dinv, h->scrA, out, s, nullptr));
+    if (!linv_t) linv_t = h->scrA;
+    GPX_TRY(build_linv_t(L, mp, h->mblk, Dinv, linv_t, s, nullptr));
     dim3 grid((unsigned)((mp + 31) / 32), (unsigned)((mp + 31) / 32));
-    hipLaunchKernelGGL(scale_transpose_kernel, grid, dim3(256), 0, s, (const double *)h->scrA, (long)mp, (long)mp, (long)mp, (const double *)nullptr,
+    hipLaunchKernelGGL(scale_transpose_kernel, grid, dim3(256), 0, s, (const double *)linv_t, (long)mp, (long)mp, (long)mp, (const double *)nullptr,
                        out, (long)mp);
     GPX_HIP(hipGetLastError());
     return 0;
@@ -222,10 +224,10 @@ static int spgp_linv(gpx_spgp *h, const double *L, const double *Dinv, double *o
 // Z <- K_NM L^-T as ONE product with the explicit inverse: inv(L) (M x M, lower) is cheap next to the N M^2 solve, and
 // K_NM inv(L)^T is a K = M GEMM on 128 x 128 tiles that skips the zero triangle of the inverse (70 TFLOP/s) where the
 // recursive TRSM issues M / 128 leaf products and short-K updates over N rows (45-50 TFLOP/s) after a 4 GB copy of K_NM.
-static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv, double *linv_keep = nullptr)
+static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv, double *linv_keep = nullptr, double *linv_t_keep = nullptr)
 {
     double *linv = linv_keep ? linv_keep : h->scrB;
-    GPX_TRY(spgp_linv(h, L, Dinv, linv));
+    GPX_TRY(spgp_linv(h, L, Dinv, linv, linv_t_keep));   // linv_t_keep: where the caller wants inv(L)^T left (default: scratch)
     return launch_gemm_nt(h->Knm, h->mpad, linv, h->mpad, h->Z, h->mpad, h->npad, h->mpad, h->mpad, 1.0, 0.0, 0, h->stream, nullptr, 0, 0,
                           GEMM_TRI_B_LOWER);
 }
@@ -596,7 +598,8 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
 
         GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
         if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
-        GPX_TRY(spgp_solve_into_z(h, L, Dinv));                                                     // Z = Zt = V^T
+        double *LinvT = h->scrA;                                                                    // inv(L)^T, explicit and upper triangular: kept for the products below
+        GPX_TRY(spgp_solve_into_z(h, L, Dinv, nullptr, LinvT));                                     // Z = Zt = V^T
         GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, junk, gam, s, nullptr));   // gamma = v + vt - |V_n|^2
         GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, gam, nullptr, isq, junk, s));                  // isq = 1 / sqrt(ep), ep = gamma / vt
         GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, isq, yh, nullptr, s));
@@ -622,8 +625,6 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         GPX_TRY(spgp_wtw(h, W2, Qb, 1.0, -1.0));
         GPX_TRY(launch_symmetrize_lower(Qb, mp, mp, s));
         hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
-        // L^-T (explicit, upper triangular) is still in scrA from spgp_solve_into_z above
-        const double *LinvT = h->scrA;
         GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_UPPER));   // Z = Kbar^T = Vbar^T L^-1 (L^-T upper: half the contraction)
         GPX_TRY(launch_gemm_nt(LinvT, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Y = L^-T Qb   (Qb symmetric)
         GPX_TRY(launch_gemm_nt(Y, mp, LinvT, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Qbar = L^-T Qb L^-1

@@ -47,6 +47,35 @@ class Covariance(object):
         raise NotImplementedError
 
     # ---- hyper-parameter maximum likelihood ("next" row f1; skgpuppy/Covariance.py:189-337) ----------------
+    def _log_det_cov_matrix(self, x, theta):
+        """log det of cov_matrix(x, theta) (Covariance.py:189-195: numpy slogdet); here 2 sum log diag of its Cholesky factor,
+        computed on the GPU from the operator's own matrix"""
+        K = _gpx.f64(self.cov_matrix(x, theta))
+        out = np.empty_like(K)
+        ld = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_spd_inverse(_gpx.ptr(K), K.shape[0], _gpx.ptr(out), ctypes.byref(ld)), "gpx_spd_inverse")
+        return ld.value
+
+    def _d_cov_d_theta(self, xi, xj, theta, j):
+        """central difference of the scalar kernel in theta_j, eps = 1e-5 (Covariance.py:219-233)"""
+        eps = 1e-5
+        d = np.zeros(len(theta))
+        d[j] = eps
+        return (self(xi, xj, theta + d) - self(xi, xj, theta - d)) / (2 * eps)
+
+    def _d_cov_matrix_d_theta_ij(self, xi, xj, theta, j):
+        """entry-wise _d_cov_d_theta (Covariance.py:236-253); GaussianCovariance overrides it with the closed form"""
+        ni, nj = len(xi), len(xj)
+        K = np.zeros((ni, nj))
+        for i1 in range(ni):
+            for i2 in range(nj):
+                K[i1, i2] = self._d_cov_d_theta(xi[i1], xj[i2], theta, j)
+        return K
+
+    def _d_cov_matrix_d_theta(self, x, theta, j):
+        # (Covariance.py:256-265)
+        return self._d_cov_matrix_d_theta_ij(x, x, theta, j)
+
     def _negativeloglikelihood(self, x, t, theta):
         raise NotImplementedError
 
@@ -151,6 +180,55 @@ class GaussianCovariance(Covariance):
             return model.kinv()
         finally:
             model.close()
+
+    def _log_det_cov_matrix(self, x, theta):
+        """log det (K + vt I) (Covariance.py:189-195) from the Cholesky factor of a device fit"""
+        from .GaussianProcess import _DeviceModel
+        xa = _gpx.f64(x)
+        model = _DeviceModel(xa, np.zeros(xa.shape[0]), _theta(theta, xa.shape[1]))
+        try:
+            return model.logdet()
+        finally:
+            model.close()
+
+    def _d_cov_d_theta(self, xi, xj, theta, j):
+        """d k(xi, xj) / d theta_j in closed form (Covariance.py:485-503); theta is the LOG of (v, vt, w): j = 0 -> the
+        noise-free kernel, j = 1 -> vt iff xi == xj elementwise, j >= 2 -> -1/2 (dx_k)^2 w_k k"""
+        xi = np.asarray(xi, dtype=float)
+        xj = np.asarray(xj, dtype=float)
+        diff = xi - xj
+        with np.errstate(divide="ignore"):
+            v = np.exp(theta[0])
+            vt = np.exp(theta[1])
+            w = np.exp(np.asarray(theta[2:], dtype=float))
+        kf = v * np.exp(-0.5 * np.dot(diff, w * diff))
+        if j == 0:
+            return kf
+        if j == 1:
+            return vt if (xi == xj).all() else 0
+        return -0.5 * diff[j - 2] ** 2 * kf * w[j - 2]
+
+    def _d_cov_matrix_d_theta(self, x, theta, j):
+        # (Covariance.py:505-512)
+        if j == 1:
+            with np.errstate(divide="ignore"):
+                return np.eye(np.shape(x)[0]) * np.exp(theta[1])
+        return self._d_cov_matrix_d_theta_ij(x, x, theta, j)
+
+    def _d_cov_matrix_d_theta_ij(self, xi, xj, theta, j, Cov=None):
+        """derivative Gram d K_ij / d theta_j (Covariance.py:605-657): the noise-free Gram from the HIP kernel (or `Cov` when
+        the caller has it), scaled entry-wise by -1/2 w_k (xi_k - xj_k)^2 for j = k + 2.  An accessor: the likelihood gradient
+        itself never forms these matrices (nll_grad_kernel)."""
+        a = _gpx.f64(xi)
+        b = _gpx.f64(xj)
+        if j == 1:
+            return np.zeros((a.shape[0], b.shape[0]))
+        K = np.asarray(Cov, dtype=float) if Cov is not None else self.cov_matrix_ij(a, b, theta)
+        if j == 0:
+            return K
+        w = np.exp(np.asarray(theta[2:], dtype=float))
+        dk = a[:, j - 2][:, None] - b[:, j - 2][None, :]
+        return -0.5 * K * (dk * dk) * w[j - 2]
 
     def _model_at(self, x, t, theta):
         """device model fitted at theta, cached on (x, t, theta) identity/bytes: L-BFGS-B asks for the value and the
@@ -337,21 +415,48 @@ class SPGPCovariance(Covariance):
         """the Woodbury inverse (Covariance.py:835-863); `cov_matrix` is ignored as in the reference."""
         return self._fit_model(x, None, theta).dense(1)
 
+    @staticmethod
+    def _signature(a):
+        """content signature of an array: its bytes while that is cheap (<= 8 MB), else shape + strides + a strided sample of
+        ~64 k elements that always includes both ends -- an in-place refill of a large buffer changes it with near certainty"""
+        if a is None:
+            return None
+        a = np.asarray(a)
+        if a.nbytes <= (8 << 20):
+            return (a.shape, a.dtype.str, hash(a.tobytes()))
+        flat = a.reshape(-1) if a.flags.c_contiguous else a.ravel()
+        step = max(1, flat.size // 65536)
+        return (a.shape, a.strides, a.dtype.str, hash(flat[::step].tobytes()), hash(flat[-64:].tobytes()))
+
     def _fit_model(self, x, t, theta):
         """the device model of (x, t, theta), kept until the next different request: L-BFGS asks for the likelihood and
-        its gradient at the same theta, one after the other"""
-        xa = np.asarray(x)
-        # identity of the arrays, plus their content while that is cheap to hash (an array mutated in place keeps its id)
-        sig = (hash(xa.tobytes()), None if t is None else hash(np.asarray(t).tobytes())) if xa.size <= (1 << 20) else None
-        key = (id(x), id(t), sig, _gpx.f64(theta).tobytes())
+        its gradient at the same theta, one after the other.  The key is the CONTENT of x, t and theta (t is always hashed
+        in full: it is only N doubles); `clear_cache()` releases the device buffers, and `ml_estimate` does so when it is done."""
+        key = (self._signature(x), self._signature(t), _gpx.f64(theta).tobytes())
         cached = getattr(self, "_fit_cache", None)
         if cached is None or cached[0] != key:
             if cached is not None:
                 cached[1].close()
             self._fit_cache = None
-            cached = (key, self._model(x, t, theta), x, t)        # (x, t kept alive: their ids are part of the key)
+            cached = (key, self._model(x, t, theta))
             self._fit_cache = cached
         return cached[1]
+
+    def clear_cache(self):
+        """release the cached device models (K_NM, Z, W^T and the M x M buffers: about 3 N M doubles)"""
+        for name in ("_fit_cache", "_cross_model"):
+            cached = getattr(self, name, None)
+            if cached is not None:
+                cached[1].close()
+            setattr(self, name, None)
+
+    close = clear_cache
+
+    def ml_estimate(self, x, t):
+        try:
+            return Covariance.ml_estimate(self, x, t)
+        finally:
+            self.clear_cache()
 
     def _negativeloglikelihood(self, x, t, theta):
         """Snelson's O(N m^2) likelihood (Covariance.py:981-1019); raises LinAlgError like the reference's Cholesky."""

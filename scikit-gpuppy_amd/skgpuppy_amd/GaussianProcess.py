@@ -157,15 +157,28 @@ class GaussianProcess(object):
         global generator (so np.random.seed governs it as in the reference -- the streams themselves differ, the
         distribution is the same).  size=k returns k draws as rows."""
         n, d = np.shape(x)
-        if isinstance(cov, SPGPCovariance) or not isinstance(cov, GaussianCovariance):
+        if type(cov) is not GaussianCovariance:
+            # any other operator (SPGP, a user subclass that overrides cov_matrix): the reference's own route on ITS matrix
             K = cov.cov_matrix(x, theta)
             return np.random.multivariate_normal(np.zeros(n), K, size)
-        model = _DeviceModel(_gpx.f64(x), np.zeros(n), _gpx.f64(theta))
+        z = np.random.standard_normal((1 if size is None else int(size), n))
         try:
-            z = np.random.standard_normal((1 if size is None else int(size), n))
-            draws = model.chol_mul(z)
+            model = _DeviceModel(_gpx.f64(x), np.zeros(n), _gpx.f64(theta))
+        except np.linalg.LinAlgError:
+            model = None
+        try:
+            if model is not None and model.jitter() == 0.0:
+                draws = model.chol_mul(z)
+                return draws[0] if size is None else draws
         finally:
-            model.close()
+            if model is not None:
+                model.close()
+        # K is numerically semi-definite (noise-free or tiny-vt kernels): the Cholesky route would sample from K + 1e-5 I (the
+        # fit's documented retry) or fail.  numpy's SVD-based sampler accepts such K, as in the reference: the Gram matrix still
+        # comes from the HIP kernel, the draw uses the z already taken from the global generator's stream position.
+        K = cov.cov_matrix(x, theta)
+        u_, s_, _vh = np.linalg.svd(K, hermitian=True)
+        draws = z.dot((u_ * np.sqrt(np.maximum(s_, 0.0))).T)
         return draws[0] if size is None else draws
 
     def __call__(self, x_star):

@@ -55,6 +55,7 @@ SIGNATURES = {
     "gpx_cjh": (_int, [_hp, _dp, _dp, _dp, _dp]),
     "gpx_propagate_approx": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 4),
     "gpx_propagate_approx_rows": (_int, [_hp, _dp, _dp, _i64, _i64, _dp]),
+    "gpx_propagate_approx_rhs": (_int, [_hp, _dp, _dp, _int, _int, _dp]),
     "gpx_propagate_dvh": (_int, [_hp, _dp, _dp]),
     "gpx_propagate_exact": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_propagate_exact_rows": (_int, [_hp, _dp, _dp, _i64, _i64, _dp]),

@@ -132,7 +132,39 @@ class TorchComm(object):
         self.rank = dist.get_rank(group)
         self.split_bytes = split_bytes
         self.exercise_single_rank = exercise_single_rank     # tests: issue the collectives even in a group of one rank
-        self._split_ok = os.environ.get("GPX_PANEL_BROADCAST", "split") != "plain"   # "plain": one dist.broadcast per panel
+        self.nccl = dist.get_backend(group) == "nccl"
+        # The transport is chosen ONCE, here, by all ranks together, and never changes afterwards: a rank that switched
+        # collectives in the middle of the panel sequence would leave its peers inside a different collective (a hang, not an
+        # error).  "plain" (GPX_PANEL_BROADCAST=plain, or the probe below failing on any rank): one dist.broadcast per panel.
+        self._split_ok = os.environ.get("GPX_PANEL_BROADCAST", "split") != "plain"
+        if self._split_ok and self.nccl and (self.world > 1 or exercise_single_rank):
+            self._split_ok = self._probe_split()
+
+    def _probe_split(self):
+        """one tiny scatter + in-place all-gather on device tensors; the verdict is the minimum over the ranks"""
+        import torch
+        dist = self.dist
+        ok = 1
+        try:
+            buf = torch.zeros(self.world * 2, dtype=torch.float64, device="cuda")
+            if self.rank == 0:
+                buf += torch.arange(self.world * 2, dtype=torch.float64, device="cuda") + 1.0
+            parts = list(buf.view(self.world, 2).unbind(0))
+            dist.scatter(parts[self.rank], scatter_list=parts if self.rank == 0 else None, src=0, group=self.group)
+            dist.all_gather_into_tensor(buf, parts[self.rank], group=self.group)
+            torch.cuda.synchronize()
+            if not torch.equal(buf.cpu(), torch.arange(self.world * 2, dtype=torch.float64) + 1.0):
+                ok = 0
+        except (RuntimeError, ValueError, TypeError) as exc:
+            sys.stderr.write("[skgpuppy_amd.distributed] scatter + all-gather unavailable on rank %d (%s)\n" % (self.rank, exc))
+            ok = 0
+        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        agreed = bool(int(t.item()))
+        if not agreed and self.rank == 0:
+            sys.stderr.write("[skgpuppy_amd.distributed] panel transport: plain broadcast\n")
+        return agreed
 
     def broadcast(self, buf, src, ops=None):
         dist = self.dist
@@ -141,21 +173,18 @@ class TorchComm(object):
             n = buf.numel()
             if self.world == 1 and not self.exercise_single_rank:
                 return _Work([])
-            if n * buf.element_size() < self.split_bytes or n % self.world:
+            if not self._split_ok or n * buf.element_size() < self.split_bytes or n % self.world:
                 return _Work([dist.broadcast(buf, src=src, group=self.group, async_op=True)])
             parts = list(buf.view(self.world, n // self.world).unbind(0))
             mine = parts[self.rank]
-            if dist.get_backend(self.group) == "nccl":
-                if self._split_ok:
-                    try:
-                        # both collectives are queued on RCCL's stream in this order
-                        w1 = dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group, async_op=True)
-                        w2 = dist.all_gather_into_tensor(buf, mine.clone(), group=self.group, async_op=True)
-                        return _Work([w1, w2])
-                    except (RuntimeError, ValueError, TypeError) as exc:   # argument validation: the same on every rank
-                        self._split_ok = False
-                        sys.stderr.write("[skgpuppy_amd.distributed] scatter + all-gather unavailable (%s): plain broadcast\n" % exc)
-                return _Work([dist.broadcast(buf, src=src, group=self.group, async_op=True)])
+            if self.nccl:
+                # Both collectives run on RCCL's own stream in the order they are posted.  The all-gather is the IN-PLACE form
+                # (its input is this rank's chunk of its output): it reads the chunk on that same stream, after the scatter
+                # has written it.  (A copy of the chunk made on the posting stream would race with the scatter and spread the
+                # slot's previous contents.)  No fallback here: an error after the scatter is posted must surface.
+                w1 = dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(buf, mine, group=self.group, async_op=True)
+                return _Work([w1, w2])
             # CPU backends (gloo rehearsal) do not order two asynchronous collectives: run them one after the other
             dist.scatter(mine, scatter_list=parts if self.rank == src else None, src=src, group=self.group)
             return _Work([dist.all_gather(parts, mine.clone(), group=self.group, async_op=True)])
@@ -398,6 +427,17 @@ def combine_approx_partials(o, Sigma, v, vt):
     return mu, s2 + var2 + var3, s2, var2 + var3
 
 
+def rhs_shards(nvec, world):
+    """[k0, k1) of the nvec right-hand sides each rank solves for: contiguous, as even as possible, empty for surplus ranks"""
+    per, extra = divmod(nvec, world)
+    out, k = [], 0
+    for r in range(world):
+        n = per + (1 if r < extra else 0)
+        out.append((k, k + n))
+        k += n
+    return out
+
+
 def row_shards(n, world, triangular=False):
     """[lo, hi) per rank: 128-aligned row panels of (almost) equal height -- or, with `triangular`, of (almost) equal AREA
     of the lower triangle (row i of the Exact propagation's j <= i double sum costs i + 1 pairs)."""
@@ -530,20 +570,32 @@ class ShardedGaussianProcess(object):
                    "gpx_propagate_approx")
         return out[0].value + self.meant, out[1].value
 
-    def propagate_GA_sharded(self, u, Sigma):
-        """ONE propagation shared by all ranks (collective): rank r passes over its row panel of K^-1 only -- (K^-1 v)_i
-        and every quadratic form of skgpuppy/UncertaintyPropagation.py:412-479 are sums over the rows -- and the 4 + 2 d
-        partial sums meet in one all-reduce.  K^-1 is materialised per rank on first use, so this is the path for MANY
-        propagations on one fit (inverse propagation, design studies): each call then reads 1/R of K^-1 per GPU."""
+    def propagate_GA_sharded(self, u, Sigma, via="solve"):
+        """ONE propagation shared by all ranks (collective); the 4 + 2 d partial sums of
+        skgpuppy/UncertaintyPropagation.py:412-479 meet in one all-reduce.
+
+        via="solve" (default): the d + 1 right-hand sides [C, J_1..J_d] are dealt to the ranks, each rank runs the two-sweep
+            triangular solver on ITS vectors against its copy of the factor (gpx_propagate_approx_rhs).  No rank ever
+            materialises K^-1 (34 GB and ~3 s of N^3 work per rank at N = 65536).
+        via="kinv": rank r passes over its row panel of K^-1 only ((K^-1 v)_i and every quadratic form are sums over the rows;
+            gpx_propagate_approx_rows).  K^-1 is built per rank on first use: the path for MANY propagations on one fit
+            (inverse propagation, design studies), where each call then reads 1/R of K^-1 per GPU."""
         import torch
         import torch.distributed as dist
         from . import _gpx
         u = _gpx.f64(u)
         S = _gpx.f64(Sigma)
-        lo, hi = row_shards(self.n, self.world)[self.rank]
         part = np.zeros(4 + 2 * self.d)
-        _gpx.check(_gpx.lib.gpx_propagate_approx_rows(self._h, _gpx.ptr(u), _gpx.ptr(S), lo, hi, _gpx.ptr(part)),
-                   "gpx_propagate_approx_rows")
+        if via == "kinv":
+            lo, hi = row_shards(self.n, self.world)[self.rank]
+            _gpx.check(_gpx.lib.gpx_propagate_approx_rows(self._h, _gpx.ptr(u), _gpx.ptr(S), lo, hi, _gpx.ptr(part)),
+                       "gpx_propagate_approx_rows")
+        elif via == "solve":
+            k0, k1 = rhs_shards(self.d + 1, self.world)[self.rank]
+            _gpx.check(_gpx.lib.gpx_propagate_approx_rhs(self._h, _gpx.ptr(u), _gpx.ptr(S), k0, k1, _gpx.ptr(part)),
+                       "gpx_propagate_approx_rhs")
+        else:
+            raise ValueError("via must be 'solve' or 'kinv'")
         tot = torch.as_tensor(part)
         if self._on_device:
             tot = tot.to(self.device)
@@ -666,19 +718,27 @@ def bench_main(args):
         vq = torch.empty(M, dtype=torch.float64, device=dev)
         vp = lambda tt: ctypes.c_void_p(tt.data_ptr())  # noqa: E731
         th = np.ascontiguousarray(theta, dtype=np.float64)
-        best = None
-        for _rep in range(2):           # first repetition warms this path's allocations
+        # the same protocol as the sharded legs: args.warmup untimed steps, then args.steps timed ones
+        acc = [0.0, 0.0]
+        for rep in range(args.warmup + args.steps):
             h1 = ctypes.c_void_p()
+            torch.cuda.synchronize()
             a = time.perf_counter()
             _gpx.check(_gpx.lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h1)), "gpx_fit (1-GPU reference)")
             b = time.perf_counter()
             _gpx.check(_gpx.lib.gpx_predict(h1, vp(xq), M, vp(mq), vp(vq)), "gpx_predict (1-GPU reference)")
+            torch.cuda.synchronize()
             c = time.perf_counter()
             _gpx.lib.gpx_free(h1)
-            best = (c - a, b - a, c - b)
+            if rep >= args.warmup:
+                acc[0] += b - a
+                acc[1] += c - b
         _gpx.lib.gpx_pool_trim()
-        one_gpu = {"ms_per_step": best[0] * 1e3, "fit_ms": best[1] * 1e3, "predict_ms": best[2] * 1e3,
-                   "value": (N + M) / best[0], "note": "same workload, one GPU, single-GPU library path, timed on rank 0 after the timed region"}
+        k_ = float(max(1, args.steps))
+        one_gpu = {"ms_per_step": (acc[0] + acc[1]) / k_ * 1e3, "fit_ms": acc[0] / k_ * 1e3, "predict_ms": acc[1] / k_ * 1e3,
+                   "value": (N + M) * k_ / (acc[0] + acc[1]), "steps": args.steps, "warmup": args.warmup,
+                   "note": "same workload, one GPU, single-GPU library path (= bench.py --gpus 1 --workload %s), timed on rank 0 "
+                           "after the sharded legs with the same warm-up / step counts" % (args.workload or "c4")}
     dist.barrier()
     if rank == 0:
         flops = N ** 3 / 3.0 + float(N) * N * M

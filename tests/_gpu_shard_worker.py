@@ -20,6 +20,8 @@ def main():
     dist.init_process_group("gloo")
     rank = dist.get_rank()
     N, d, M = int(sys.argv[1]), int(sys.argv[2]), 333
+    light = len(sys.argv) > 3 and sys.argv[3] == "light"     # large N: against the single-GPU path only (the oracle's LU inverse of
+                                                             # that size on two host threads would take minutes)
     rng = np.random.RandomState(20240 + N + d)
     x = rng.uniform(0, 10, (N, d))
     t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
@@ -32,38 +34,46 @@ def main():
     if rank == 0:
         ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
         m1, v1 = ref.estimate_many(xs)
-        og = orc.OracleGP(x, t, theta)
-        om, ov = og.estimate_many(xs)
         e1 = max(np.abs(mean - m1).max(), np.abs(var - v1).max())
-        e2 = max(np.abs(mean - om).max(), np.abs(var - ov).max())
-        print("sharded vs single-GPU: %.3e   sharded vs oracle: %.3e" % (e1, e2))
-        ok = e1 < 1e-10 and np.allclose(mean, om, rtol=1e-6, atol=1e-9) and np.allclose(var, ov, rtol=1e-6, atol=2e-9)
+        if light:
+            print("sharded vs single-GPU: %.3e   (%d ranks, %d panels)" % (e1, dist.get_world_size(), gp.layout.npanels))
+            ok = e1 < 1e-9
+        else:
+            og = orc.OracleGP(x, t, theta)
+            om, ov = og.estimate_many(xs)
+            e2 = max(np.abs(mean - om).max(), np.abs(var - ov).max())
+            print("sharded vs single-GPU: %.3e   sharded vs oracle: %.3e" % (e1, e2))
+            ok = e1 < 1e-10 and np.allclose(mean, om, rtol=1e-6, atol=1e-9) and np.allclose(var, ov, rtol=1e-6, atol=2e-9)
     # propagation on the replicated factor: calls sharded over the ranks, every rank gets every result
     us = np.array([[5.0] * d, [4.0] * d, [6.5] * d, x[3]])
     Ss = [0.01 * np.eye(d)] * 4
     pm, pv = gp.propagate_many(us, Ss)
     if rank == 0:
         up = sk.UncertaintyPropagationApprox(ref)
-        og_ = orc.OracleGP(x, t, theta)
+        og_ = None if light else orc.OracleGP(x, t, theta)
         for i in range(4):
             want = up.propagate_GA(us[i], Ss[i])
-            owant = orc.approx_propagate(og_, us[i], Ss[i])
             ok = ok and abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9
-            ok = ok and abs(pm[i] - owant[0]) < 1e-8 and abs(pv[i] - owant[1]) < 2e-8
+            if not light:
+                owant = orc.approx_propagate(og_, us[i], Ss[i])
+                ok = ok and abs(pm[i] - owant[0]) < 1e-8 and abs(pv[i] - owant[1]) < 2e-8
         print("sharded propagate_many vs single-GPU and oracle:", ok)
     # ONE propagation shared by the ranks: row panels of K^-1, 4 + 2 d partial sums, one all-reduce (last row)
     for i in (0, 3):
-        sm, sv = gp.propagate_GA_sharded(us[i], Ss[i])
-        if rank == 0:
-            owant = orc.approx_propagate(og_, us[i], Ss[i])
-            ok = ok and abs(sm - pm[i]) < 1e-9 and abs(sv - pv[i]) < 1e-9
-            ok = ok and abs(sm - owant[0]) < 1e-8 and abs(sv - owant[1]) < 2e-8
+        for via in ("solve", "kinv"):      # right-hand sides dealt to the ranks (no K^-1 anywhere) / row panels of K^-1
+            sm, sv = gp.propagate_GA_sharded(us[i], Ss[i], via=via)
+            if rank == 0:
+                ok = ok and abs(sm - pm[i]) < 1e-9 and abs(sv - pv[i]) < 1e-9
+                if not light:
+                    owant = orc.approx_propagate(og_, us[i], Ss[i])
+                    ok = ok and abs(sm - owant[0]) < 1e-8 and abs(sv - owant[1]) < 2e-8
         em, ev = gp.propagate_exact_sharded(us[i], Ss[i])
         if rank == 0:
             ewant = sk.UncertaintyPropagationExact(ref).propagate_GA(us[i], Ss[i])
-            eo = orc.exact_propagate(og_, us[i], Ss[i])
             ok = ok and abs(em - ewant[0]) < 1e-9 and abs(ev - ewant[1]) < 1e-9
-            ok = ok and abs(em - eo[0]) < 1e-8 and abs(ev - eo[1]) < 2e-8
+            if not light:
+                eo = orc.exact_propagate(og_, us[i], Ss[i])
+                ok = ok and abs(em - eo[0]) < 1e-8 and abs(ev - eo[1]) < 2e-8
     if rank == 0:
         print("row-sharded propagate_GA / Exact vs call-sharded, single-GPU and oracle:", ok)
     flag = torch.tensor([1.0 if ok else 0.0])

@@ -36,7 +36,11 @@ def test_row_shards_and_partial_combination():
     propagate_GA (the device side of the same partials is covered by the -m gpu two-rank test)."""
     import numpy as np
     from oracle import oracle as orc
-    from skgpuppy_amd.distributed import combine_approx_partials, row_shards
+    from skgpuppy_amd.distributed import combine_approx_partials, rhs_shards, row_shards
+    for nvec, world in ((9, 2), (17, 8), (3, 8), (65, 3)):
+        sh = rhs_shards(nvec, world)
+        assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == nvec
+        assert all(a[1] == b[0] for a, b in zip(sh, sh[1:])) and max(b - a for a, b in sh) - min(b - a for a, b in sh) <= 1
     for n, world in ((1000, 3), (128, 2), (16384, 8), (5, 4)):
         sh = row_shards(n, world)
         assert sh[0][0] == 0 and sh[-1][1] == n and all(a[1] == b[0] for a, b in zip(sh, sh[1:]))

@@ -458,6 +458,89 @@ def test_sharded_fit_two_ranks_share_one_gpu(N, d):
     assert "sharded vs single-GPU" in r.stdout
 
 
+def test_sharded_fit_four_ranks_share_one_gpu_c3_size():
+    """The panel-sharded path with FOUR ranks on the one GPU at the C3 size (N = 16384: 16 outer panels, every rank owns four, both
+    staging slots are reused seven times; host-staged transport) against the single-GPU path: estimate_many, call-sharded and
+    row-sharded propagation (Approx and Exact)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29737", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), "16384", "8", "light"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "sharded vs single-GPU" in r.stdout and "4 ranks, 16 panels" in r.stdout
+
+
+def test_sharded_fit_c4_size_on_rccl_world_size_one():
+    """BASELINE config 4 (N = 65536, d = 16) through the SHARDED code path on a real RCCL group of one rank (all this box offers):
+    64 outer panels through the two staging slots, RCCL-resident collectives, against the single-GPU path and the
+    size-independent checks of test_c4_full_size_properties."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = r'''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "scikit-gpuppy_amd"))
+import skgpuppy_amd as sk
+from skgpuppy_amd import _gpx
+from skgpuppy_amd.distributed import ShardedGaussianProcess
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+N, d = 65536, 16
+rng = np.random.RandomState(20240 + N + d)
+x = rng.uniform(0, 10, (N, d)); t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N); xs = rng.uniform(0, 10, (1024, d))
+theta = np.log(np.array([2.0, 0.01] + [0.04] * d)); v, vt = 2.0, 0.01
+gp = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0))
+assert gp.layout.npanels == 64 and gp.jitter == 0.0
+rows = np.random.RandomState(1).choice(N, 512, replace=False)
+mean, var = gp.estimate_many(x[rows])                               # interpolation identity: var in [vt, 2 vt)
+assert np.all(var >= vt - 1e-9) and np.all(var < 2 * vt)
+mf, vf = gp.estimate_many(np.full((1, d), 1e3))                      # prior far away
+assert abs(mf[0] - gp.meant) < 1e-12 and abs(vf[0] - (v + vt)) < 1e-12
+ms, vs = gp.estimate_many(xs)
+pa = gp.propagate_GA(xs[0], 1e-14 * np.eye(d))                        # Sigma -> 0: the plain prediction
+assert abs(pa[0] - ms[0]) < 1e-8 and abs(pa[1] - vs[0]) < 1e-7
+gp.close(); _gpx.lib.gpx_pool_trim()
+ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+m1, v1 = ref.estimate_many(xs)
+beta = ref._get_beta()
+e = max(np.abs(ms - m1).max(), np.abs(vs - v1).max())
+assert e < 1e-9, e
+np.testing.assert_allclose(mean - ref.meant, ref.t[rows] - vt * beta[rows], rtol=0, atol=1e-8)
+dist.destroy_process_group(); print("sharded C4 on RCCL world size 1 ok, max dev vs single-GPU %%.2e" %% e)
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "sharded C4 on RCCL world size 1 ok" in r.stdout
+
+
+def test_panel_transport_on_rccl_multi_gpu():
+    """TorchComm.broadcast (scatter + in-place all-gather, and the plain broadcast) between REAL GPUs: every rank receives what
+    the source sent, slot reuse included.  Needs at least two devices; the 1-GPU boxes skip it (the gloo tests cover the logic,
+    the world-size-1 test below the RCCL argument checks)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 GPUs")
+    world = min(ndev, 4)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", "29745", os.path.join(ROOT, "tests", "_nccl_bcast_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "panel transport over RCCL ok" in r.stdout
+
+
 def test_sharded_collectives_on_rccl_world_size_one():
     """The public collectives of ShardedGaussianProcess on a real RCCL (nccl) group -- RCCL has no host path, so every
     operand of all_gather / all_reduce must live on the device (one rank is all this box offers; the two-rank run above
@@ -490,6 +573,8 @@ for i in range(2):
     want = up.propagate_GA(us[i], Ss[i])
     got = gp.propagate_GA_sharded(us[i], Ss[i])
     assert abs(pm[i] - want[0]) < 1e-9 and abs(pv[i] - want[1]) < 1e-9 and abs(got[0] - want[0]) < 1e-9 and abs(got[1] - want[1]) < 1e-9
+    got = gp.propagate_GA_sharded(us[i], Ss[i], via="kinv")
+    assert abs(got[0] - want[0]) < 1e-9 and abs(got[1] - want[1]) < 1e-9
     ew = sk.UncertaintyPropagationExact(ref).propagate_GA(us[i], Ss[i])
     eg = gp.propagate_exact_sharded(us[i], Ss[i])
     assert abs(eg[0] - ew[0]) < 1e-9 and abs(eg[1] - ew[1]) < 1e-9
@@ -1033,3 +1118,80 @@ def test_jitter_fallback_on_the_lookahead_path():
     assert gp2._dev().jitter() == 1e-5
     with pytest.raises(ValueError):      # scipy.linalg.inv's check_finite raises ValueError in the reference as well
         sk.GaussianProcess(x, t, sk.GaussianCovariance(), np.array([np.nan, -1.0, -1.0, -1.0, -1.0]))
+
+
+# ------------------------------------------------------------------------------------------------
+# operator surface: derivative Grams, log det, quadratic-form helpers
+# ------------------------------------------------------------------------------------------------
+def test_derivative_grams_and_logdet_golden():
+    """GaussianCovariance._d_cov_matrix_d_theta(_ij), _d_cov_d_theta, _log_det_cov_matrix against the reference's own outputs
+    (skgpuppy/Covariance.py:485-512, :605-657, :189-195; fixtures from tools/gen_golden.py)."""
+    g = load_golden("gram")
+    cov = sk.GaussianCovariance()
+    for name, sq in (("n257_d5", True), ("rect_33x257_d5", False), ("n130_d1", True)):
+        xi, xj, th = g[name + "__xi"], g[name + "__xj"], g[name + "__theta"]
+        if name == "n257_d5":
+            xi = xj = xi[:130]
+        for j in range(len(th)):
+            want = g["%s__dKij_%d" % (name, j)]
+            got = cov._d_cov_matrix_d_theta_ij(xi, xj, th, j)
+            np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-13 * np.abs(want).max() + 1e-300, err_msg="%s j=%d" % (name, j))
+            if sq and ("%s__dK_%d" % (name, j)) in g:
+                np.testing.assert_allclose(cov._d_cov_matrix_d_theta(xi, th, j), g["%s__dK_%d" % (name, j)], rtol=1e-11, atol=1e-13)
+        if sq:
+            assert abs(cov._log_det_cov_matrix(xi, th) - float(g[name + "__logdet"])) < 1e-8 * max(1.0, abs(float(g[name + "__logdet"])))
+            # the base-class route (Cholesky of the operator's own matrix on the GPU) agrees
+            assert abs(sk.Covariance._log_det_cov_matrix(cov, xi, th) - float(g[name + "__logdet"])) < 1e-8 * max(1.0, abs(float(g[name + "__logdet"])))
+    th = g["scalar__theta"]
+    for (a, b), want in zip(g["scalar__pairs"], g["scalar__dcov"]):
+        for j in range(len(th)):
+            assert abs(cov._d_cov_d_theta(a, b, th, j) - want[j]) <= 1e-13 * max(1.0, abs(want[j]))
+
+
+def test_gaussian_cov_derivative_mirrors_reference_test():
+    """skgpuppy/tests/tests.py:485-503: the closed-form scalar derivative against the base class's central difference, delta 1e-3"""
+    x = np.atleast_2d(np.linspace(0, 10, 50)).T
+    theta = np.log(np.array([2.0, 0.01, 0.02]))
+    cov = sk.GaussianCovariance()
+    for xi in x[::7]:
+        for xj in x[::5]:
+            for j in range(3):
+                assert abs(sk.Covariance._d_cov_d_theta(cov, xi, xj, theta, j) - cov._d_cov_d_theta(xi, xj, theta, j)) < 1e-3
+    # and the generic matrix form built from it agrees with the closed-form derivative Gram
+    xs = x[::10]
+    for j in (0, 2):
+        np.testing.assert_allclose(sk.Covariance._d_cov_matrix_d_theta_ij(cov, xs, xs, theta, j), cov._d_cov_matrix_d_theta_ij(xs, xs, theta, j),
+                                   atol=1e-6)
+
+
+def test_approx_helper_methods_golden(case):
+    """_get_sigma2 / _get_variance_rest / _get_sigma2_and_variance_rest (UncertaintyPropagation.py:412-488) against the oracle's
+    parts, and the Exact class's scalar correction factors against the oracle's l_i / L_ij building blocks."""
+    name, g, gp = case
+    og = orc.OracleGP(g["x"], g["t_raw"], g["theta"])
+    k = _loose(name)
+    up = sk.UncertaintyPropagationApprox(gp)
+    d = gp.d
+    for iu in range(int(g["nu"])):
+        u = g["u%d" % iu]
+        for iS in range(int(g["nS"])):
+            S = g["Sigma%d" % iS]
+            _m, o_s2, o_rest = orc.approx_parts(og, u, S)
+            s2, rest = up._get_sigma2_and_variance_rest(u, S, gp.Kinv, gp.x, gp._get_beta())
+            tol = 1e-8 * gp._get_v() * k
+            assert abs(s2 - o_s2) < tol and abs(rest - o_rest) < tol
+            assert abs(up._get_sigma2(u, gp.Kinv, gp.x, up.C_ux, up.J_ux, up.H_ux) - o_s2) < tol
+            assert abs(up._get_variance_rest(u, S, gp.Kinv, gp.x, gp._get_beta(), up.C_ux, up.J_ux, up.H_ux) - o_rest) < tol
+            # the reference's own number that is made of exactly these two: _getFactor = (v_out - sigma2) / rest
+            assert (float(g["v_out"]) - s2) / rest == pytest.approx(float(g["factor_u%d_S%d" % (iu, iS)]), rel=1e-5 * k)
+    ue = sk.UncertaintyPropagationExact(gp)
+    u, S = g["u0"], g["Sigma0"]
+    ue.propagate_GA(u, S)
+    w = np.exp(g["theta"][2:2 + d])
+    a = u - np.asarray(g["x"], dtype=float)[3]
+    Delta_inv = np.diag(w) - np.diag(w / (1 + w * np.diag(S)))
+    want1 = np.exp(0.5 * a @ Delta_inv @ a) / np.sqrt(np.linalg.det(np.eye(d) + np.diag(w) * S))
+    Lam_inv = 2 * np.diag(w) - np.linalg.inv(0.5 * np.diag(1 / w) + S)
+    want2 = np.exp(0.5 * a @ Lam_inv @ a) / np.sqrt(np.linalg.det(2 * np.diag(w) * S + np.eye(d)))
+    assert abs(ue._get_C_corr(u, g["x"][3]) - want1) <= 1e-12 * abs(want1)
+    assert abs(ue._get_C_corr2(u, g["x"][3]) - want2) <= 1e-12 * abs(want2)

@@ -206,3 +206,18 @@ def test_spgp_analytic_gradient_matches_central_differences():
             e[j] = 1e-6
             fd[j] = (orc.spgp_nll(x, t, theta + e, m) - orc.spgp_nll(x, t, theta - e, m)) / 2e-6
         np.testing.assert_allclose(g, fd, rtol=0, atol=5e-7 * np.abs(g).max())
+
+
+def test_oracle_derivative_grams_against_reference_vectors():
+    """oracle.d_gram_d_theta (the building block of the oracle's likelihood gradient) against the reference's
+    _d_cov_matrix_d_theta outputs (Covariance.py:505-512, :605-657); log det against _log_det_cov_matrix (:189-195)."""
+    g = load_golden("gram")
+    for name in ("n257_d5", "n130_d1"):
+        x, th = g[name + "__xi"], g[name + "__theta"]
+        if name == "n257_d5":
+            x = x[:130]
+        for j in (0, 1, len(th) - 1):
+            want = g["%s__dK_%d" % (name, j)]
+            np.testing.assert_allclose(orc.d_gram_d_theta(x, th, j), want, rtol=1e-10, atol=1e-13 * np.abs(want).max() + 1e-300)
+        og = orc.OracleGP(x, np.zeros(len(x)), th)
+        assert abs(og.logdet() - float(g[name + "__logdet"])) < 1e-8 * max(1.0, abs(float(g[name + "__logdet"])))

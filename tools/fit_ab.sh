@@ -8,7 +8,7 @@ cd $GRAFT_REPO_ROOT
 i=0
 while [ $# -gt 0 ] && [ "$1" != "--" ]; do
     envs="$1"; shift
-    line=$(env $envs python bench.py --no-cpu --no-python-api --no-propagate --steps 10 --warmup 3 2> $OUT/ab_$i.err | tail -1)
+    line=$(env $envs python bench.py --no-cpu --no-python-api --no-propagate --no-extras --steps 10 --warmup 3 2> $OUT/ab_$i.err | tail -1)
     echo "$line" > $OUT/ab_$i.json
     python - "$envs" "$OUT/ab_$i.json" <<'PY'
 import json, sys
@@ -25,7 +25,7 @@ if [ "$1" == "--" ]; then
     envs="$1"
     cd /tmp && export TMPDIR=/tmp
     export $envs
-    rocprofv3 --kernel-trace -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-propagate --no-cpu --no-python-api --warmup 1 --steps 3 > $OUT/trace_line.json 2> $OUT/trace.err
+    rocprofv3 --kernel-trace -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-propagate --no-extras --no-cpu --no-python-api --warmup 1 --steps 3 > $OUT/trace_line.json 2> $OUT/trace.err
     cd $GRAFT_REPO_ROOT
     db=$(ls $OUT/trace/*/*.db $OUT/trace/*.db 2>/dev/null | head -1)
     python tools/fit_timeline.py $db 2 > $OUT/timeline.txt 2>&1

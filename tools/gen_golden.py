@@ -20,7 +20,7 @@ import types
 import numpy as np
 
 REF = os.environ.get("GPX_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("GPX_GOLDEN_OUT", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden"))
 
 
 def _install_shims():
@@ -92,6 +92,20 @@ def gram_cases(GC):
             out["%s__K_ij" % name] = cov.cov_matrix_ij(xi, xj, th)
             if xi is xj:
                 out["%s__K" % name] = cov.cov_matrix(xi, th)
+    # derivative Grams and log det of the operator interface (Covariance.py:485-512, :605-657, :189-195; the reference's
+    # test_gaussian_cov_derivative, tests/tests.py:485-503, checks the scalar form against central differences)
+    x130 = x257[:130]
+    for name, xi, xj, th in (("n257_d5", x130, x130, th5), ("rect_33x257_d5", x33, x257, th5), ("n130_d1", x1, x1, np.array([0.0, -4.0, 2.0]))):
+        for j in range(len(th)):
+            out["%s__dKij_%d" % (name, j)] = cov._d_cov_matrix_d_theta_ij(xi, xj, th, j)
+            if xi is xj and j in (0, 1, len(th) - 1):      # (the square form differs from the rectangular one only for j = 1)
+                out["%s__dK_%d" % (name, j)] = cov._d_cov_matrix_d_theta(xi, th, j)
+        if xi is xj:
+            out["%s__logdet" % name] = np.float64(cov._log_det_cov_matrix(xi, th))     # n257_d5: its first 130 rows
+    pairs = [(x33[0], x33[0]), (x33[0], x33[1]), (x33[5], x33[9])]
+    out["scalar__pairs"] = np.array([[a, b] for a, b in pairs])
+    out["scalar__theta"] = th5
+    out["scalar__dcov"] = np.array([[cov._d_cov_d_theta(a, b, th5, j) for j in range(len(th5))] for a, b in pairs], dtype=float)
     return out
 
 
