@@ -409,6 +409,39 @@ def test_c2_full_size_against_oracle():
     np.testing.assert_allclose(gp.Kinv[::97, ::89], og.Kinv[::97, ::89], rtol=0, atol=1e-6 * np.abs(og.Kinv).max())
 
 
+def test_c3_fit_and_propagation_against_oracle():
+    """BASELINE config 3 (N = 16384, d = 8: fit + propagate_GA) at FULL size against the oracle: its LU inverse of K (seconds to a
+    minute on the host's BLAS threads), then approx_propagate / exact_propagate in the serial loop order of
+    UncertaintyPropagation2.pyx on that K^-1 (about 10 s and 60 s).  u = 5 1_d, Sigma = 0.01 I; SURVEY 8a tolerances.
+    Both device paths of the Approx class are checked: the two-sweep solver right after the fit and the pass over K^-1."""
+    N, d = 16384, 8
+    x, t, xs, theta = _recipe(N, d, 64)
+    v = 2.0
+    u, S = np.full(d, 5.0), 0.01 * np.eye(d)
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    ga_solve = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)          # solver path: no K^-1 yet
+    ge = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)                  # materialises K^-1
+    ga_kinv = sk.UncertaintyPropagationApprox(gp).propagate_GA(u + 0.0, S)      # same u: cached; a new object, new-u path below
+    ga_kinv2 = sk.UncertaintyPropagationApprox(gp).propagate_GA(u + 0.25, S)
+    mean, var = gp.estimate_many(xs)
+    beta = gp._get_beta()
+    gp._dev().close()
+    _gpx.lib.gpx_pool_trim()
+    og = orc.OracleGP(x, t, theta)
+    om, ov = og.estimate_many(xs)
+    np.testing.assert_allclose(mean, om, rtol=1e-6, atol=1e-9 * v)
+    np.testing.assert_allclose(var, ov, rtol=1e-6, atol=1e-9 * v)
+    obeta = og.beta()
+    np.testing.assert_allclose(beta, obeta, rtol=0, atol=1e-6 * np.abs(obeta).max())
+    oa = orc.approx_propagate(og, u, S)
+    for got in (ga_solve, ga_kinv):
+        assert got[0] == pytest.approx(oa[0], abs=1e-9) and got[1] == pytest.approx(oa[1], abs=1e-8 * v)
+    oa2 = orc.approx_propagate(og, u + 0.25, S)
+    assert ga_kinv2[0] == pytest.approx(oa2[0], abs=1e-9) and ga_kinv2[1] == pytest.approx(oa2[1], abs=1e-8 * v)
+    oe = orc.exact_propagate(og, u, S)
+    assert ge[0] == pytest.approx(oe[0], abs=1e-9) and ge[1] == pytest.approx(oe[1], abs=1e-8 * v)
+
+
 def test_c4_full_size_properties():
     """BASELINE config 4 (N = 65536, d = 16; K = 34 GB) on ONE GPU through the user-facing classes: the oracle cannot run
     this size (2 N^3 = 5.6e14 flop), so the checks are the size-independent ones of test_full_size_properties."""
