@@ -361,36 +361,44 @@ template <int NB, int J> __device__ __forceinline__ void elim_pivot(double (&d)[
     if constexpr (J + 1 < 16) elim_pivot<NB, J + 1>(d, gi, b, piv, c);
 }
 
-// left-looking update of one 16 x 16 block of the current panel: A[ib][jb] - sum_{k < jb} L[ib][k] L[jb][k]^T, in accumulator
-// layout (lane (fq, fr): rows fq + 4 r, column fr), fragments of step k + 1 read while the MFMAs of step k run
-__device__ __forceinline__ v4d leaf_block_update(const double *X, int ib, int jb, int fr, int fq)
+// left-looking update of NB (1..2) 16 x 16 blocks of the current panel at once: A[rows[q]][jb] - sum_{k < jb} L[rows[q]][k] L[jb][k]^T in
+// accumulator layout (lane (fq, fr): rows fq + 4 r, column fr).  The blocks share the fragments of L[jb][k], their MFMAs are
+// interleaved (independent accumulators), and the fragments of step k + 1 are read while the MFMAs of step k run.
+template <int NB>
+__device__ __forceinline__ void leaf_update_blocks(const double *X, const int (&rows)[2], int jb, int fr, int fq, v4d (&acc)[2])
 {
-    const double *Cb = &X[xblk(ib, jb)];
-    v4d acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = Cb[(fq + 4 * r) * 17 + fr];
-    if (jb == 0) return acc;
-    double la[2][4], lb[2][4];
-    const int rowa = xblk(ib, 0) + fr * 17 + fq, rowb = xblk(jb, 0) + fr * 17 + fq;   // blocks (i, k) of a row are XB apart
+    for (int q = 0; q < NB; ++q) {
+        const double *Cb = &X[xblk(rows[q], jb)];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { la[0][kk] = X[rowa + 4 * kk]; lb[0][kk] = X[rowb + 4 * kk]; }
+        for (int r = 0; r < 4; ++r) acc[q][r] = Cb[(fq + 4 * r) * 17 + fr];
+    }
+    if (jb == 0) return;
+    const int offb = xblk(jb, 0) + fr * 17 + fq;              // blocks (i, k) of a block row are XB apart
+    int offa[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) offa[q] = xblk(rows[q], 0) + fr * 17 + fq;
+    double lb[2][4], la[2][NB][4];
+#define GPX_LEAF_LOAD(SET, K)                                                                        \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                               \
+        lb[SET][kk] = X[offb + (K) * XB + 4 * kk];                                                   \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q) la[SET][q][kk] = -X[offa[q] + (K) * XB + 4 * kk]; \
+    }
+#define GPX_LEAF_MMA(SET)                                                                            \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                 \
+        _Pragma("unroll") for (int q = 0; q < NB; ++q)                                               \
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(la[SET][q][kk], lb[SET][kk], acc[q], 0, 0, 0);
+    GPX_LEAF_LOAD(0, 0)
     for (int k = 0; k < jb; k += 2) {
+        if (k + 1 < jb) { GPX_LEAF_LOAD(1, k + 1) }
+        GPX_LEAF_MMA(0)
         if (k + 1 < jb) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) { la[1][kk] = X[rowa + (k + 1) * XB + 4 * kk]; lb[1][kk] = X[rowb + (k + 1) * XB + 4 * kk]; }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[0][kk], lb[0][kk], acc, 0, 0, 0);
-        if (k + 1 < jb) {
-            if (k + 2 < jb) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) { la[0][kk] = X[rowa + (k + 2) * XB + 4 * kk]; lb[0][kk] = X[rowb + (k + 2) * XB + 4 * kk]; }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[1][kk], lb[1][kk], acc, 0, 0, 0);
+            if (k + 2 < jb) { GPX_LEAF_LOAD(0, k + 2) }
+            GPX_LEAF_MMA(1)
         }
     }
-    return acc;
+#undef GPX_LEAF_LOAD
+#undef GPX_LEAF_MMA
 }
 
 // elimination of one panel: the group's copy of the diagonal block d, its row gi of the appended identity, and the rows b of
@@ -464,14 +472,25 @@ __device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv,
         const int nbw = (wave < nb ? 1 : 0) + (wave + 4 < nb ? 1 : 0);
         const int ibs[2] = {jb + 1 + wave, jb + 5 + wave};
         v4d acc[2] = {(v4d){0.0, 0.0, 0.0, 0.0}, (v4d){0.0, 0.0, 0.0, 0.0}};
-        if (jb > 0 && wave == 3) {
-            const v4d dacc = leaf_block_update(X, jb, jb, fr, fq);
-            double *Db = &X[xblk(jb, jb)];
+        {
+            // wave 3 owns at most ONE block below the diagonal (block 3; a second one would be block 7 of a panel with eight blocks
+            // below): it also brings the diagonal block up to date
+            const bool diag = (jb > 0 && wave == 3);
+            const int nblk_w = nbw + (diag ? 1 : 0);            // <= 2 for every wave
+            const int rows[2] = {diag ? jb : ibs[0], diag ? ibs[0] : ibs[1]};
+            v4d a2[2];
+            if (nblk_w == 2) leaf_update_blocks<2>(X, rows, jb, fr, fq, a2);
+            else if (nblk_w == 1) leaf_update_blocks<1>(X, rows, jb, fr, fq, a2);
+            if (diag) {
+                double *Db = &X[xblk(jb, jb)];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Db[(fq + 4 * r) * 17 + fr] = dacc[r];
+                for (int r = 0; r < 4; ++r) Db[(fq + 4 * r) * 17 + fr] = a2[0][r];
+                if (nbw > 0) acc[0] = a2[1];
+            } else {
+                if (nbw > 0) acc[0] = a2[0];
+                if (nbw > 1) acc[1] = a2[1];
+            }
         }
-        if (nbw > 0) acc[0] = leaf_block_update(X, ibs[0], jb, fr, fq);
-        if (nbw > 1) acc[1] = leaf_block_update(X, ibs[1], jb, fr, fq);
         LEAF_ACC2(3, 16 + jb);
         if (jb > 0) __syncthreads();
         LEAF_ACC2(3, 24 + jb);
@@ -779,14 +798,14 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
 // retiring bulk workgroup's place -- equal-length tiles retire in bursts -- and then runs 3x (next to one bulk wave per SIMD)
 // to 10x (next to two) slower than alone; kernels small enough to be placed at once (<= 64 VGPRs, <= 16 KB of LDS) pay the
 // 10x.  Neither stream priorities nor s_setprio change that.  What does: a few CUs that the bulk cannot enter.  A "blocker"
-// workgroup of four sleeping waves that each hold 312 VGPRs leaves 200 registers per SIMD: no bulk wave (224) fits there, the
-// chain's kernels (leaf 200, 32/64-row GEMM tiles 80-122 VGPRs) do, and the whole LDS stays free.  R blockers launched on an
+// workgroup of four sleeping waves that each hold 296 VGPRs leaves 216 registers per SIMD: no bulk wave (224) fits there, the
+// chain's kernels (leaf 216, 32/64-row GEMM tiles 80-122 VGPRs) do, and the whole LDS stays free.  R blockers launched on an
 // idle chip take R distinct CUs (two cannot share one), dealt round-robin over the XCDs; they leave when the flag is set (after
 // the last bulk launch of the factorisation) or, whatever happens to the host, when their time limit expires.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cu_blocker_kernel(const int *stop, int *placed, unsigned long long limit_ticks)
 {
-    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a55, 0" ::: "v255", "a55");   // 256 VGPRs + 56 AGPRs: 312 registers per wave
+    asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a39, 0" ::: "v255", "a39");   // 256 VGPRs + 40 AGPRs: 296 registers per wave
     if (threadIdx.x == 0) __hip_atomic_fetch_add(placed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (threadIdx.x < 64) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
@@ -891,8 +910,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
         // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued now, it runs
         // underneath the first panel's chain
+        // (the first step is queued ahead of that launch: its leaf takes a CU before the Gram kernel's workgroups flood the chip)
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));
         if (after_fork) GPX_TRY((*after_fork)());
-        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 1));
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 1, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));   // nothing else fills the chip yet: every leaf finds an empty CU
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
@@ -936,7 +957,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved && !released) ? 2 : 0));
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }

@@ -28,7 +28,7 @@ if [ "$1" == "--" ]; then
     rocprofv3 --kernel-trace -d $OUT/trace -o t -- python3 $GRAFT_REPO_ROOT/bench.py --no-propagate --no-extras --no-cpu --no-python-api --warmup 1 --steps 3 > $OUT/trace_line.json 2> $OUT/trace.err
     cd $GRAFT_REPO_ROOT
     db=$(ls $OUT/trace/*/*.db $OUT/trace/*.db 2>/dev/null | head -1)
-    python tools/fit_timeline.py $db 2 > $OUT/timeline.txt 2>&1
+    python tools/fit_timeline.py $db 2 detail > $OUT/timeline.txt 2>&1
     cat $OUT/timeline.txt
     rm -rf $OUT/trace
 fi

@@ -56,5 +56,29 @@ def main():
             ("bulk %8.1f -> %8.1f (%6.1f us, %d wgs)" % ((b[1] - t0) / 1e3, (b[2] - t0) / 1e3, (b[2] - b[1]) / 1e3, b[4])) if b else ""))
 
 
+def detail(path, k):
+    """every launch of the main queue inside the fit window, with the idle time in front of it"""
+    rows = load(path)
+    seeds = [i for i, r in enumerate(rows) if "ts_seed" in r[0]]
+    i1 = seeds[k]
+    i0 = max(i for i in range(i1) if "gram_kernel" in rows[i][0])
+    for i in range(i0 - 1, max(i0 - 6, -1), -1):
+        if "gram_kernel" in rows[i][0] and rows[i0][1] - rows[i][2] < 200000:
+            i0 = i
+    t0 = rows[i0][1]
+    win = rows[i0:i1]
+    mainq = max(set(r[3] for r in win), key=lambda q: sum(r[2] - r[1] for r in win if r[3] == q and short(r[0]) in ("G44L", "G44")))
+    prev = None
+    print("main queue %d: start(us) dur(us) idle-before(us) kernel grid" % mainq)
+    for r in win:
+        if r[3] != mainq:
+            continue
+        idle = (r[1] - prev) / 1e3 if prev is not None else 0.0
+        print("  %9.1f %8.1f %8.1f  %-6s %d" % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, idle, short(r[0]), r[4] * max(1, r[5])))
+        prev = r[2]
+
+
 if __name__ == "__main__":
     main()
+    if len(sys.argv) > 3 and sys.argv[3] == "detail":
+        detail(sys.argv[1], int(sys.argv[2]))
