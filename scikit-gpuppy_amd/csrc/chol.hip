@@ -415,6 +415,10 @@ __device__ __forceinline__ void leaf_panel_eliminate(double *X, double *dinv, in
     gi = (c == g) ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) b[q] = acc[q >> 2][q & 3];
+    // every wave has its copy of the diagonal block in registers before any wave stores L_d over it below (a wave that shares its
+    // SIMD with a bulk wave can fall thousands of cycles behind its siblings: without this barrier a fast wave's store now and
+    // then reached a slow wave's load -- a wrong factor in one fit out of ~50 at N = 16384, caught by tools/probe_race.py)
+    __syncthreads();
     elim_pivot<NB, 0>(d, gi, b, piv, c);
     const double sc = fast_rsqrt(piv);           // lane c: 1 / L_cc
     // a non-positive (or NaN) pivot: first such column of the first such panel
@@ -826,6 +830,21 @@ __global__ void wait_placed_kernel(const int *placed, int want, unsigned long lo
         __builtin_amdgcn_s_sleep(16);
 }
 
+// holds its stream until the producer launch has counted `want` finished tiles in *ctr.  A time limit that expires (it never should:
+// the producer does not depend on this stream) is reported through the factorisation's status word instead of letting the consumers
+// read tiles that are not there.
+__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *info)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) {
+            __hip_atomic_fetch_max(info, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 static int reserve_cus()
 {
     static const int v = [] { const char *e = getenv("GPX_RESERVE_CUS"); const int r = e ? atoi(e) : 32; return r < 0 ? 0 : (r > 128 ? 128 : r); }();
@@ -868,6 +887,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     const int nres = reserve_cus();
     hipStream_t s_blk = nres ? stream_acquire(0) : nullptr;
     int *stop_flag = info_dev + 1, *placed = info_dev + 2;
+    static const int trap_on = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
+    int *sig = info_dev + 3;                                   // one counter per panel: finished narrow tiles of its trapezoid launch
     bool reserved = false, released = false;
     hipEvent_t ev_blk = nullptr;
     auto release_blockers = [&](hipStream_t on) {
@@ -897,6 +918,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, pure latency)
         // underneath all of that, and the third stream solves ALL rows below panel p's square column by column alongside
         // panel p's chain (TopPipe), so that neither a top slice nor a panel TRSM remains on the main stream.
+        if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)P, s));
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
@@ -939,21 +961,41 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, 1));
+            // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
+            // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
-                GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
-                                       K, -1.0, 1.0, 0, s, prof));
+                // One trapezoid launch for the next panel's columns AND the bulk SYRK (gemm.hip, launch_syrk_trap_signal): its narrow
+                // tiles come first and are counted in sig[p]; the next panel's column solves wait for the count, not for a launch
+                // boundary.  Small trailing matrices keep the two launches.
+                int merged = GPX_ERR_STATE;
+                const int64_t nrem = nblk - B2;
+                if (trap_on && nrem * (nrem + 1) / 2 >= 1024 && B2 - B1 == CHOL_NBP)
+                    merged = launch_syrk_trap_signal(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, nrem * TILE, (B2 - B1) * TILE, K, -1.0, 1.0,
+                                                     sig + p, s, prof);
+                if (merged != 0 && merged != GPX_ERR_STATE) return merged;
+                if (merged != 0)
+                    GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
+                                           K, -1.0, 1.0, 0, s, prof));
                 if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
-                    GPX_HIP(hipEventRecord(ev_tu[p], s));
-                    GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
+                    if (merged == 0) {
+                        // a one-thread kernel in front of the column solves on their own stream (host order: behind the launch; on the
+                        // device the wait runs next to it and ends with the last narrow tile).  Handing the count over as an event
+                        // from a stream of its own was measured too: one more cross-stream edge per panel, fit +1.4 ms.
+                        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, s_top, (const int *)(sig + p), (int)(nrem * (B2 - B1)), 500000000ull, info_dev);   // <= 5 s
+                    } else {
+                        GPX_HIP(hipEventRecord(ev_tu[p], s));
+                        GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
+                    }
                     GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
-                GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
-                                       (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+                if (merged != 0)
+                    GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
+                                           (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }

@@ -12,6 +12,7 @@
 // is described at the kernel.  An earlier 128x256 / one-wave-per-SIMD variant (AGPR-pinned inline-asm MFMAs, three LDS
 // buffers) topped out at 67 TFLOP/s against 75 for this one and was removed.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -30,7 +31,7 @@ __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
 // gemm_tile: one block tile (by, bx) of C over the contraction range [kstart, kend).  smem: two stages, 1024-aligned.
 template <int WM, int WN>
 __device__ __forceinline__ void gemm_tile(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int bx, int by,
-                                          long kstart, int kend, double alpha, double beta, double *smem)
+                                          long kstart, int kend, double alpha, double beta, double *smem, bool write_through = false)
 {
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
@@ -178,7 +179,19 @@ __device__ __forceinline__ void gemm_tile(const double *A, long lda, const doubl
 #undef GPX_MMA
 #undef GPX_DMA_STAGE
 
-    // epilogue: pure stores
+    // epilogue: pure stores.  write_through (wave-uniform): the tile is handed to a consumer that starts before this launch ends
+    // (gemm_nt_f64_trap_signal_kernel) -- its stores go straight through the XCD's L2 (sc1), so that publishing it needs no
+    // write-back of the whole L2 underneath the other workgroups.
+    if (write_through) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    __hip_atomic_store(&Cw[(long)(i * 16 + 4 * r) * ldc + j * 16], alpha * acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -298,6 +311,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         else if (ba.tri == GEMM_TRI_B_UPPER || ba.tri == GEMM_TRI_B_UPPER_PAIRED) kstart = (long)bx * BTN;          // B[j][k] = 0 for k < j
         gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
     }
+}
+
+// One launch for the whole trailing update of a panel: tile rows r = 0 .. nt-1 of C hold `off` full ("narrow") tile columns -- the next
+// panel's columns -- followed by the lower triangle (columns off .. off + r).  The narrow tiles used to be a launch of their own in
+// front of the bulk SYRK (up to 896 tiles = 1.75 rounds of the chip's 512 places: a quarter of the second round idle, then a launch
+// gap); here they are simply the FIRST tiles every XCD takes, the triangle's tiles fill the places behind them, and each narrow
+// tile's workgroup adds 1 to *sig once its stores are released -- the column solves of the next panel, which need exactly those
+// tiles, wait for the count on their own stream instead of for a launch boundary.
+// XCD x (workgroups with blockIdx & 7 == x) takes the narrow 8 x off groups g = x, x + 8, .. (8 tile rows each: 64 tiles that share
+// 8 A and `off` B row panels through that XCD's L2), then its contiguous chunk of the triangle in the grouped order of lower_tile.
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
+                                                                        int K, double alpha, double beta, int off, int nt, int *sig)
+{
+    __shared__ __attribute__((aligned(1024))) double smem[2 * 256 * 16];
+    const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
+    int idx = orig >> 3;                                       // this XCD's idx-th workgroup
+    const int G = (nt + 7) >> 3;
+    auto rows_of = [&](int g) { return min(8, nt - 8 * g); };
+    auto narrow_of = [&](int x) { int c = 0; for (int g = x; g < G; g += 8) c += rows_of(g) * off; return c; };
+    const int mine = narrow_of(xcd);
+    int bx, by;
+    bool narrow = idx < mine;
+    if (narrow) {
+        int g = xcd;
+        while (idx >= rows_of(g) * off) { idx -= rows_of(g) * off; g += 8; }
+        const int r = rows_of(g);
+        by = 8 * g + idx % r;                                  // column-major inside the group
+        bx = idx / r;
+    } else {
+        int start = 0;
+        for (int x = 0; x < xcd; ++x) start += (nwg - x + 7) / 8 - narrow_of(x);
+        lower_tile(start + idx - mine, 0, nt, by, bx);
+        bx += off;
+    }
+    const bool publish = narrow && sig;
+    gemm_tile<4, 4>(A, lda, B, ldb, C, ldc, bx, by, 0, K, alpha, beta, smem, publish);
+    if (publish) {
+        // The narrow tile went out as write-through (sc1) stores: every storing wave drains them, the workgroup meets, one lane
+        // counts the tile -- no write-back of the XCD's whole L2 (release fence) underneath the running bulk tiles.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// C[M, off_cols + M] (lower trapezoid by 128-tiles, see the kernel) = alpha A B^T + beta C with A [M, K], B [off_cols + M, K]; *sig_dev
+// (zero before the launch) counts the finished tiles of the first off_cols columns: (off_cols / 128) * (M / 128) in the end.
+// Returns GPX_ERR_STATE when the shape does not suit this launch (the caller then issues the two launches it replaces).
+int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
+                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof)
+{
+    if (M % TILE || off_cols % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0) {
+        gpx_set_error("launch_syrk_trap_signal: shape/alignment not supported");
+        return GPX_ERR_BAD_ARG;
+    }
+    const int64_t nt = M / TILE, off = off_cols / TILE, tri = nt * (nt + 1) / 2, nwg = tri + off * nt;
+    const int64_t G = (nt + 7) / 8;
+    for (int x = 0; x < 8; ++x) {   // every XCD must have at least as many workgroups as narrow tiles
+        int64_t c = 0;
+        for (int64_t g = x; g < G; g += 8) c += std::min<int64_t>(8, nt - 8 * g) * off;
+        if ((nwg - x + 7) / 8 < c) return GPX_ERR_STATE;
+    }
+    ProfScope ps(prof, s, GPX_K_GEMM, (double)nwg * 2.0 * TILE * TILE * (double)K, 1);
+    hipLaunchKernelGGL(gemm_nt_f64_trap_signal_kernel, dim3((unsigned)nwg), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta,
+                       (int)off, (int)nt, sig_dev);
+    GPX_HIP(hipGetLastError());
+    return 0;
 }
 
 // The 32/64-row tiles with the bulk kernel's register footprint (224 VGPRs): the same product, but the workgroup cannot settle on
@@ -735,4 +815,10 @@ extern "C" int gpx_dev_gemm_nt_sliver(const double *A, int64_t lda, const double
                                       int64_t M, int64_t N, int64_t K, double alpha, double beta, void *stream)
 {
     return launch_gemm_nt_sliver(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols,
+                                 int64_t K, double alpha, double beta, int *count_dev, void *stream)
+{
+    return launch_syrk_trap_signal(A, lda, B, ldb, C, ldc, M, off_cols, K, alpha, beta, count_dev, (hipStream_t)stream, nullptr);
 }
