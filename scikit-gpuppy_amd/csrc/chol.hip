@@ -845,6 +845,34 @@ __global__ void wait_count_kernel(const int *ctr, int want, unsigned long long l
     }
 }
 
+// The trapezoid hand-off and the CU reservation rely on kernels of DIFFERENT streams running at the same time (a one-thread kernel
+// waits for a count another launch produces; blockers sleep until a later launch releases them).  Counter-collecting profilers
+// (rocprofv3 --pmc) run one kernel at a time: the waits would sit out their time limits.  Checked once per process with a 2 ms probe: a
+// waiting kernel on one stream, the kernel that releases it launched afterwards on another.
+static bool streams_run_concurrently(hipStream_t a, hipStream_t b)
+{
+    // on the caller's own two streams (both idle here): extra streams would change which streams share a hardware queue
+    static const bool ok = [&] {
+        if (const char *e = getenv("GPX_CONCURRENT_STREAMS")) return atoi(e) != 0;
+        int *w = nullptr;
+        if (!a || !b || hipMalloc((void **)&w, 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        bool good = false;
+        if (hipMemset(w, 0, 2 * sizeof(int)) == hipSuccess) {
+            hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, a, (const int *)w, 1, 200000ull, w + 1);   // <= 2 ms
+            hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, b, w, 1);
+            int h[2] = {0, 1};
+            if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+                hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+                good = (h[1] == 0);
+        }
+        (void)hipGetLastError();
+        (void)hipFree(w);
+        if (getenv("GPX_DEBUG")) fprintf(stderr, "[gpx] concurrent-streams probe: %d\n", (int)good);
+        return good;
+    }();
+    return ok;
+}
+
 static int reserve_cus()
 {
     static const int v = [] { const char *e = getenv("GPX_RESERVE_CUS"); const int r = e ? atoi(e) : 32; return r < 0 ? 0 : (r > 128 ? 128 : r); }();
@@ -884,10 +912,14 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
     // CU reservation (above) for the tail of the factorisation: flag and placement counter live behind the status word; the
     // blockers run on a stream of their own
-    const int nres = reserve_cus();
+    // (the waiting kernel on the chain's stream, its release on the main stream: the order in which the fit first uses its streams --
+    // the runtime binds a stream to a hardware queue at its first launch, and another order was measured to cost 5 ms per fit)
+    const bool concurrent = streams_run_concurrently(s_pan, s);
+    const int nres = concurrent ? reserve_cus() : 0;
     hipStream_t s_blk = nres ? stream_acquire(0) : nullptr;
     int *stop_flag = info_dev + 1, *placed = info_dev + 2;
-    static const int trap_on = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
+    static const int trap_env = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
+    const int trap_on = trap_env && concurrent;
     int *sig = info_dev + 3;                                   // one counter per panel: finished narrow tiles of its trapezoid launch
     bool reserved = false, released = false;
     hipEvent_t ev_blk = nullptr;
@@ -932,8 +964,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
         // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued now, it runs
         // underneath the first panel's chain
-        // (the first step is queued ahead of that launch: its leaf takes a CU before the Gram kernel's workgroups flood the chip)
-        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));
+        // (the first step is queued ahead of that launch; its leaf is NOT exclusive: the Gram kernel, released on the main stream at
+        // the same moment, usually wins the race for the places, and an exclusive leaf would then wait for the whole launch to drain)
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 0));
         if (after_fork) GPX_TRY((*after_fork)());
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 1, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));   // nothing else fills the chip yet: every leaf finds an empty CU
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));

@@ -20,6 +20,8 @@ def short(n):
         return "LEAF"
     if "persistent" in n:
         return "G44P"
+    if "trap_signal" in n:
+        return "TRAP"
     m = re.search(r"gemm_nt_f64_kernelILi(\d)ELi(\d)ELb(\d)", n)
     if m:
         return "G%s%s%s" % (m.group(1), m.group(2), "L" if m.group(3) == "1" else "")
@@ -44,7 +46,7 @@ def main():
         qs.setdefault(r[3], []).append(r)
     for qid, lst in qs.items():
         print("  queue %d: %4d launches, busy %.2f ms" % (qid, len(lst), sum(r[2] - r[1] for r in lst) / 1e6))
-    bulk = [r for r in win if short(r[0]) in ("G44L", "G44P")]
+    bulk = [r for r in win if short(r[0]) in ("G44L", "G44P", "TRAP")]
     print("bulk launches: total %.2f ms" % (sum(r[2] - r[1] for r in bulk) / 1e6))
     leaves = [r for r in win if "potrf" in r[0]]
     for p in range(0, len(leaves), 8):
@@ -67,7 +69,7 @@ def detail(path, k):
             i0 = i
     t0 = rows[i0][1]
     win = rows[i0:i1]
-    mainq = max(set(r[3] for r in win), key=lambda q: sum(r[2] - r[1] for r in win if r[3] == q and short(r[0]) in ("G44L", "G44")))
+    mainq = max(set(r[3] for r in win), key=lambda q: sum(r[2] - r[1] for r in win if r[3] == q and short(r[0]) in ("G44L", "G44", "TRAP")))
     prev = None
     print("main queue %d: start(us) dur(us) idle-before(us) kernel grid" % mainq)
     for r in win:
