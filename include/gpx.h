@@ -210,8 +210,8 @@ int gpx_dev_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_
                            int64_t M, int64_t N, int64_t K, double alpha, double beta, void *stream);
 /* the trailing update of a factorisation panel as ONE launch: C [M, off_cols + M] = alpha A B^T + beta C with A [M, K], B [off_cols + M, K];
  * by 128-tiles, tile row r holds the first off_cols / 128 columns in full and then the lower triangle (r + 1 tiles).  The tiles of the
- * first off_cols columns are computed first and counted in *count_dev (device int, zero before the call) as they finish: a consumer
- * on another stream may start on them as soon as the count reaches (off_cols / 128) * (M / 128).  Returns GPX_ERR_STATE (-4) when
+ * first off_cols columns are computed first and counted per tile column in count_dev[0 .. off_cols / 128) (device ints, zero before the
+ * call) as they finish: a consumer on another stream may start on tile column c as soon as count_dev[c] reaches M / 128.  Returns GPX_ERR_STATE (-4) when
  * the shape is too small for this launch. */
 int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols,
                       int64_t K, double alpha, double beta, int *count_dev, void *stream);

@@ -401,14 +401,47 @@ extern "C" void gpx_free(gpx_handle *h)
     delete h;
 }
 
+// policy of the work that rides along with the factorisation (env GPX_FIT_RIDE=0: everything after it, as before round 3)
+static int fit_ride_enabled()
+{
+    static const int v = [] { const char *e = getenv("GPX_FIT_RIDE"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
 static int factor_once(gpx_handle *h, double add_diag, int *info_host)
 {
     hipStream_t s = h->stream;
     GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
     const int64_t c1 = CHOL_PANEL_COLS;
+    // y = L^-1 t rides along: the solver's diagonal squares are inverted and the forward substitution advances panel by panel on
+    // the main stream while that stream would otherwise idle underneath the tail's diagonal chains (chol.hip: panel_final); only
+    // the last panel's share and the backward sweep remain after the factorisation.  In the bulk-bound early panels nothing is
+    // queued (the main stream is the critical path there): the first call of the tail catches up, four panels at a time.
+    GPX_TRY(h->tri.attach(h->L, h->npad, h->nblk, h->Dinv));
+    GPX_TRY(h->tri.forward_begin(h->t, h->npad, 1, s));
+    int64_t pending = 0;                                       // first outer panel the substitution has not passed yet
+    bool finished = false;
+    const std::function<int(int64_t, int64_t, bool)> ride = [&](int64_t p_final, int64_t slack, bool last) -> int {
+        if (!last && (!fit_ride_enabled() || slack > 5)) return 0;
+        const int64_t upto = last ? p_final + 1 : std::min<int64_t>(p_final + 1, pending + 4);
+        if (upto > pending) {
+            GPX_TRY(h->tri.invert_squares(pending, upto, s, &h->prof));
+            ProfScope ps(&h->prof, s, GPX_K_TRSV, 0.0);
+            for (int64_t p = pending; p < upto; ++p) GPX_TRY(h->tri.forward_step(p, s));
+            pending = upto;
+        }
+        // the last call also queues the backward sweep: the factorisation's own stream synchronisation and clean-up on the host
+        // (200 us) then run underneath it instead of in front of it.  Should the factorisation have failed, alpha is rubbish that
+        // the retry (or the error return) discards.
+        if (last && pending == h->tri.P && !finished) {
+            GPX_TRY(h->tri.finish(h->npad, 1, h->y, h->alpha, s, &h->prof));
+            finished = true;
+        }
+        return 0;
+    };
     if (h->npad <= c1 || !h->s_pan) {
         GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
-        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top));
+        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, nullptr, &ride));
     } else {
         // the first panel's columns now; the rest of the (lower) Gram matrix underneath the first panel's diagonal chain
         GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, std::min<int64_t>(h->n, c1), h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, c1, s, &h->prof));
@@ -417,8 +450,9 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
             return launch_gram(xr, h->n - c1, xr, h->n - c1, h->d, h->v, add_diag, 1, 2, h->L + c1 * h->npad + c1, h->npad, h->npad - c1,
                                h->npad - c1, s, &h->prof);
         };
-        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, &rest));
+        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, &rest, &ride));
     }
+    GPX_TRY(ride(h->tri.P - 1, 0, true));                      // whatever the factorisation's schedule left over
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
@@ -504,8 +538,10 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
         }
     }
     // y = L^-1 t, alpha = L^-T y: the solver's diagonal-square inverses are kept for the propagation right after a fit
-    if ((rc = h->tri.prepare(h->L, h->npad, h->nblk, h->Dinv, s, &h->prof))) return fail(rc);
-    if ((rc = h->tri.solve(h->t, h->npad, 1, h->y, h->alpha, s, &h->prof))) return fail(rc);
+    if (ext) {   // (gpx_fit: both sweeps were queued by factor_once)
+        if ((rc = h->tri.prepare(h->L, h->npad, h->nblk, h->Dinv, s, &h->prof))) return fail(rc);
+        if ((rc = h->tri.solve(h->t, h->npad, 1, h->y, h->alpha, s, &h->prof))) return fail(rc);
+    }
     FIT_HIP(hipStreamSynchronize(s));
 #undef FIT_HIP
     *out = h;

@@ -672,11 +672,16 @@ static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 // Optional pipelining of the "top slice": the rows [r0, r1) below the square (the next panel's diagonal-square rows) are
 // solved against the square's triangle column by column on a second stream, each column as soon as the chain step that
 // produces its diagonal-block inverse has finished -- instead of one recursive TRSM after the whole chain.
+__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *info);
+
 struct TopPipe {
     hipStream_t stream = nullptr;
     int64_t r0 = 0, r1 = 0;                 // block rows of the slice
     std::vector<hipEvent_t> *events = nullptr;   // owned by the caller, destroyed after the final synchronisation
     int big = 0;                            // 3: tiles with the bulk kernel's register footprint (see the CU reservation in chol_factor)
+    const int *colsig = nullptr;            // column c of the slice may be read once colsig[c] has reached colwant (the trapezoid launch's
+    int colwant = 0;                        // per-column counters); null: the stream is ordered behind the update some other way
+    int *info = nullptr;
 };
 
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
@@ -687,6 +692,8 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
     // with CUs reserved for the chain these launches take the bulk kernel's 128 x 128 tiles (224 VGPRs): they must not
     // settle on the reserved CUs, where the chain's own small kernels would then queue behind them
     const int big = top->big;
+    if (top->colsig)   // a one-thread kernel in front of the column's solve (on the device it runs next to the trapezoid launch)
+        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + (j - B0), top->colwant, 500000000ull, top->info);   // <= 5 s
     if (j > B0)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
                                -1.0, 1.0, 0, top->stream, prof, big));
@@ -887,12 +894,15 @@ static long reserve_below_tiles()
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
-                hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork)
+                hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork,
+                const std::function<int(int64_t, int64_t, bool)> *panel_final)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr) {
         if (after_fork) GPX_TRY((*after_fork)());
-        return (nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
-                                  : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof);
+        GPX_TRY((nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
+                                   : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof));
+        if (panel_final) GPX_TRY((*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true));
+        return 0;
     }
     // outer panel boundaries (block units).  Wider early panels (12..32 blocks) were measured and are slower.
     std::vector<int64_t> Bs{0};
@@ -920,7 +930,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     int *stop_flag = info_dev + 1, *placed = info_dev + 2;
     static const int trap_env = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
     const int trap_on = trap_env && concurrent;
-    int *sig = info_dev + 3;                                   // one counter per panel: finished narrow tiles of its trapezoid launch
+    int *sig = info_dev + 3;                                   // CHOL_NBP counters per panel: finished narrow tiles of its trapezoid launch by tile column
     bool reserved = false, released = false;
     hipEvent_t ev_blk = nullptr;
     auto release_blockers = [&](hipStream_t on) {
@@ -950,7 +960,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, pure latency)
         // underneath all of that, and the third stream solves ALL rows below panel p's square column by column alongside
         // panel p's chain (TopPipe), so that neither a top slice nor a panel TRSM remains on the main stream.
-        if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)P, s));
+        if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP), s));
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
@@ -974,7 +984,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
-            if (B1 >= nblk) break;
+            if (B1 >= nblk) {
+                if (panel_final) GPX_TRY((*panel_final)(p, 0, true));
+                break;
+            }
             if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
                 GPX_TRY(reserve_now());
                 {   // the column solves stay off the reserved CUs (top_column)
@@ -1008,17 +1021,18 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 const int64_t nrem = nblk - B2;
                 if (trap_on && nrem * (nrem + 1) / 2 >= 1024 && B2 - B1 == CHOL_NBP)
                     merged = launch_syrk_trap_signal(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, nrem * TILE, (B2 - B1) * TILE, K, -1.0, 1.0,
-                                                     sig + p, s, prof);
+                                                     sig + p * CHOL_NBP, s, prof);
                 if (merged != 0 && merged != GPX_ERR_STATE) return merged;
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                            K, -1.0, 1.0, 0, s, prof));
                 if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     if (merged == 0) {
-                        // a one-thread kernel in front of the column solves on their own stream (host order: behind the launch; on the
-                        // device the wait runs next to it and ends with the last narrow tile).  Handing the count over as an event
+                        // every column solve waits for its own column's narrow tiles (top_column).  Handing the count over as an event
                         // from a stream of its own was measured too: one more cross-stream edge per panel, fit +1.4 ms.
-                        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, s_top, (const int *)(sig + p), (int)(nrem * (B2 - B1)), 500000000ull, info_dev);   // <= 5 s
+                        tops[p + 1].colsig = sig + p * CHOL_NBP;
+                        tops[p + 1].colwant = (int)nrem;
+                        tops[p + 1].info = info_dev;
                     } else {
                         GPX_HIP(hipEventRecord(ev_tu[p], s));
                         GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
@@ -1035,6 +1049,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
+            // work of the caller that rides along on the main stream (behind this panel's trailing update; queued after the chain's
+            // launches so that the chain's stream never waits for the host)
+            if (panel_final) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
         }
         return 0;
     };

@@ -90,7 +90,17 @@ struct TriSolver {
     double *Pl = nullptr, *Pz = nullptr;   // [P][1024][1024] inverses of the diagonal squares and their transposes
     double *T = nullptr;                   // [P][512][512] scratch of the doubling levels
     double *W = nullptr, *Y = nullptr;     // [32 npad] right-hand sides / solutions in the pair-major layout
+    int cur_ng = 0;                        // stepwise forward substitution in flight: right-hand sides / 16 (0 = none)
     int prepare(const double *L, int64_t ld, int64_t nblk, const double *Dinv, hipStream_t s, Profiler *prof);
+    // prepare in pieces (the fit runs them underneath the factorisation's tail): buffers only / squares [p0, p1) of a factor whose
+    // outer panels p0..p1-1 are final on stream s
+    int attach(const double *L, int64_t ld, int64_t nblk, const double *Dinv);
+    int invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof);
+    // forward substitution in steps of one outer panel: begin (pack), step p (needs square p and the factor's columns of panel p),
+    // finish = the rest of solve() (Yout / backward sweep / Aout)
+    int forward_begin(const double *B, int64_t ldb, int nrhs, hipStream_t s);
+    int forward_step(int64_t p, hipStream_t s);
+    int finish(int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof);
     // B [nrhs][ldb] (right-hand sides as rows, nrhs <= 32) -> Yout = L^-1 B and / or Aout = L^-T L^-1 B (null = skip)
     int solve(const double *B, int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof);
     int mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hipStream_t s);   // OUT = L B (rows, nrhs <= 32)
@@ -173,7 +183,11 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
 constexpr int64_t CHOL_PANEL_COLS = 8 * 128;   // outer panel width (CHOL_NBP tiles)
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
                 hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr,
-                const std::function<int()> *after_fork = nullptr);
+                const std::function<int()> *after_fork = nullptr,
+                const std::function<int(int64_t, int64_t, bool)> *panel_final = nullptr);
+// panel_final(p, slack, last): queued on the main stream s at a point where the columns of the outer panels 0..p are final for work
+// on s; slack = outer panels whose trailing update is still to come (small = the main stream is about to idle underneath the chain:
+// the place for work that rides along), last = the factorisation has nothing more to queue
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,

@@ -317,14 +317,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 // panel's columns -- followed by the lower triangle (columns off .. off + r).  The narrow tiles used to be a launch of their own in
 // front of the bulk SYRK (up to 896 tiles = 1.75 rounds of the chip's 512 places: a quarter of the second round idle, then a launch
 // gap); here they are simply the FIRST tiles every XCD takes, the triangle's tiles fill the places behind them, and each narrow
-// tile's workgroup adds 1 to *sig once its stores are released -- the column solves of the next panel, which need exactly those
-// tiles, wait for the count on their own stream instead of for a launch boundary.
+// tile's workgroup adds 1 to sig[its tile column] once its stores are released -- the solve of the next panel's column j, which needs
+// exactly the nt tiles of column j, waits for that count on its own stream instead of for a launch boundary (one counter per column:
+// with CUs reserved for the chain an XCD has fewer places than narrow tiles, and the last column's tiles finish a whole tile later).
 // XCD x (workgroups with blockIdx & 7 == x) takes the narrow 8 x off groups g = x, x + 8, .. (8 tile rows each: 64 tiles that share
 // 8 A and `off` B row panels through that XCD's L2), then its contiguous chunk of the triangle in the grouped order of lower_tile.
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
                                                                         int K, double alpha, double beta, int off, int nt, int *sig)
 {
     __shared__ __attribute__((aligned(1024))) double smem[2 * 256 * 16];
+    // 224 registers like the plain bulk kernel (the compiler gets by with 208 here): a wave of this kernel must NOT fit into the 216
+    // registers the CU blockers leave per SIMD (chol.hip), or one workgroup of every trapezoid launch settles on each reserved CU and
+    // the chain's leaf (which needs that CU's LDS) waits for it -- measured: leaves 100-170 us instead of 35 in the reserved panels
+    asm volatile("v_mov_b32 v223, 0" ::: "v223");
     const int nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7;
     int idx = orig >> 3;                                       // this XCD's idx-th workgroup
     const int G = (nt + 7) >> 3;
@@ -352,12 +357,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const d
         // counts the tile -- no write-back of the XCD's whole L2 (release fence) underneath the running bulk tiles.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sig, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sig + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one counter per tile column
     }
 }
 
-// C[M, off_cols + M] (lower trapezoid by 128-tiles, see the kernel) = alpha A B^T + beta C with A [M, K], B [off_cols + M, K]; *sig_dev
-// (zero before the launch) counts the finished tiles of the first off_cols columns: (off_cols / 128) * (M / 128) in the end.
+// C[M, off_cols + M] (lower trapezoid by 128-tiles, see the kernel) = alpha A B^T + beta C with A [M, K], B [off_cols + M, K]; sig_dev[c]
+// (off_cols / 128 ints, zero before the launch) counts the finished tiles of tile column c of the first off_cols columns: M / 128 each in the end.
 // Returns GPX_ERR_STATE when the shape does not suit this launch (the caller then issues the two launches it replaces).
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
                             double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof)

@@ -189,12 +189,12 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(const double *__restrict
 //     T^T = Z11 L21^T ,   inv21 = -inv22 T ,   Z12 = -T^T inv22^T        (three batched NT GEMMs, Z = inverse^T)
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__ L, long ld, long nblk, const double *__restrict__ Dinv,
-                                                     double *__restrict__ Pl, double *__restrict__ Pz)
+                                                     double *__restrict__ Pl, double *__restrict__ Pz, int p_first)
 {
     // blockIdx.x: [0, 28) sub-diagonal tiles (copy of L), [28, 36) diagonal tiles (copy of Dinv), [36, 68) transposed
     // diagonal tiles, a 32-row strip each
     __shared__ double tr[4][32][33];
-    const int bx = blockIdx.x, p = blockIdx.y, t = threadIdx.x;
+    const int bx = blockIdx.x, p = p_first + blockIdx.y, t = threadIdx.x;
     const int c2 = (t & 63) * 2, r4 = t >> 6;                 // 4 rows x 64 column pairs per pass
     if (bx < 28) {
         int ti = 1;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__
         for (int r = ty; r < 32; r += 8) dz[(long)(32 * q + r) * PB + sr + tx] = tr[q][tx][r];
 }
 
-int TriSolver::prepare(const double *L_, int64_t ld_, int64_t nblk_, const double *Dinv_, hipStream_t s, Profiler *prof)
+int TriSolver::attach(const double *L_, int64_t ld_, int64_t nblk_, const double *Dinv_)
 {
     release();
     L = L_; ld = ld_; nblk = nblk_; Dinv = Dinv_;
@@ -251,27 +251,40 @@ int TriSolver::prepare(const double *L_, int64_t ld_, int64_t nblk_, const doubl
         release();
         return rc;
     }
-    auto body = [&]() -> int {
-        ProfScope ps(prof, s, GPX_K_TRSV, 0.0);
-        hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)P), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, Pl, Pz);
-        GPX_HIP(hipGetLastError());
-        for (int64_t h = TILE; h < PB; h *= 2) {
-            const int64_t nq = PB / (2 * h);                  // pairs per square
-            GemmBatch ba, bb, bc;
-            const int64_t sp = (int64_t)PB * PB, sq = 2 * h * (PB + 1);
-            // T^T = Z11 L21^T
-            ba = {(int)nq, sp, sq, GEMM_TRI_A_UPPER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, nq * h * h, h * h, 0};
-            GPX_TRY(launch_gemm_nt_batched(Pz, PB, ba, Pl + h * PB, PB, bb, T, h, bc, h, h, h, 1.0, 0.0, P * nq, s));
-            // inv21 = -inv22 T   (over the slot that held L21)
-            ba = {(int)nq, sp, sq, GEMM_TRI_A_LOWER}; bb = {(int)nq, nq * h * h, h * h, 0}; bc = {(int)nq, sp, sq, 0};
-            GPX_TRY(launch_gemm_nt_batched(Pl + h * PB + h, PB, ba, T, h, bb, Pl + h * PB, PB, bc, h, h, h, -1.0, 0.0, P * nq, s));
-            // Z12 = -T^T inv22^T
-            ba = {(int)nq, nq * h * h, h * h, GEMM_TRI_B_LOWER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, sp, sq, 0};
-            GPX_TRY(launch_gemm_nt_batched(T, h, ba, Pl + h * PB + h, PB, bb, Pz + h, PB, bc, h, h, h, -1.0, 0.0, P * nq, s));
-        }
-        return 0;
-    };
-    rc = body();
+    return 0;
+}
+
+// squares [p0, p1): every launch is batched over that range only (the fit inverts the early squares underneath the factorisation's
+// tail, the last one after it)
+int TriSolver::invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof)
+{
+    if (!Pl || p0 < 0 || p1 > P || p0 >= p1) { gpx_set_error("TriSolver::invert_squares: bad range"); return GPX_ERR_BAD_ARG; }
+    ProfScope ps(prof, s, GPX_K_TRSV, 0.0);
+    const int64_t np = p1 - p0, sp = (int64_t)PB * PB;
+    double *pl = Pl + p0 * sp, *pz = Pz + p0 * sp, *tt = T + p0 * (int64_t)(PB / 2) * (PB / 2);
+    hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)np), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, Pl, Pz, (int)p0);
+    GPX_HIP(hipGetLastError());
+    for (int64_t h = TILE; h < PB; h *= 2) {
+        const int64_t nq = PB / (2 * h);                  // pairs per square
+        GemmBatch ba, bb, bc;
+        const int64_t sq = 2 * h * (PB + 1);
+        // T^T = Z11 L21^T
+        ba = {(int)nq, sp, sq, GEMM_TRI_A_UPPER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, nq * h * h, h * h, 0};
+        GPX_TRY(launch_gemm_nt_batched(pz, PB, ba, pl + h * PB, PB, bb, tt, h, bc, h, h, h, 1.0, 0.0, np * nq, s));
+        // inv21 = -inv22 T   (over the slot that held L21)
+        ba = {(int)nq, sp, sq, GEMM_TRI_A_LOWER}; bb = {(int)nq, nq * h * h, h * h, 0}; bc = {(int)nq, sp, sq, 0};
+        GPX_TRY(launch_gemm_nt_batched(pl + h * PB + h, PB, ba, tt, h, bb, pl + h * PB, PB, bc, h, h, h, -1.0, 0.0, np * nq, s));
+        // Z12 = -T^T inv22^T
+        ba = {(int)nq, nq * h * h, h * h, GEMM_TRI_B_LOWER}; bb = {(int)nq, sp, sq, 0}; bc = {(int)nq, sp, sq, 0};
+        GPX_TRY(launch_gemm_nt_batched(tt, h, ba, pl + h * PB + h, PB, bb, pz + h, PB, bc, h, h, h, -1.0, 0.0, np * nq, s));
+    }
+    return 0;
+}
+
+int TriSolver::prepare(const double *L_, int64_t ld_, int64_t nblk_, const double *Dinv_, hipStream_t s, Profiler *prof)
+{
+    GPX_TRY(attach(L_, ld_, nblk_, Dinv_));
+    const int rc = invert_squares(0, P, s, prof);
     if (rc) {
         (void)hipStreamSynchronize(s);   // launches already queued may still use the buffers
         release();
@@ -289,32 +302,71 @@ void TriSolver::release()
     Pl = Pz = W = Y = T = nullptr;
     L = Dinv = nullptr;
     P = 0;
+    cur_ng = 0;
 }
 
 template <int NG>
-static int ts_sweeps(const TriSolver *ts, bool backward, hipStream_t s)
+static void ts_forward_step(const TriSolver *ts, int64_t p, hipStream_t s)
 {
     constexpr int NC = 16 * NG;
     const int64_t npad = ts->npad, ld = ts->ld;
-    if (!backward) {
-        for (int64_t p = 0; p < ts->P; ++p) {
-            const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0), below = npad - k0 - K;
-            hipLaunchKernelGGL((ts_rows_kernel<NG, TS_LOWER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pl + p * (int64_t)PB * PB, (long)PB,
-                               (int)K, ts->W + k0 * NC, ts->Y + k0 * NC);
-            if (below > 0)
-                hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPDATE>), dim3((unsigned)(below / 16)), dim3(256), 0, s, ts->L + (k0 + K) * ld + k0, (long)ld,
-                                   (int)K, ts->Y + k0 * NC, ts->W + (k0 + K) * NC);
-        }
-    } else {
-        // residual = Y (destroyed), solution -> W
-        for (int64_t p = ts->P - 1; p >= 0; --p) {
-            const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0);
-            hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPPER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pz + p * (int64_t)PB * PB, (long)PB,
-                               (int)K, ts->Y + k0 * NC, ts->W + k0 * NC);
-            if (k0 > 0)
-                hipLaunchKernelGGL((ts_cols_kernel<NG>), dim3((unsigned)(k0 / 32)), dim3(512), 0, s, ts->L + k0 * ld, (long)ld, (int)K,
-                                   ts->W + k0 * NC, ts->Y);
-        }
+    const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0), below = npad - k0 - K;
+    hipLaunchKernelGGL((ts_rows_kernel<NG, TS_LOWER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pl + p * (int64_t)PB * PB, (long)PB,
+                       (int)K, ts->W + k0 * NC, ts->Y + k0 * NC);
+    if (below > 0)
+        hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPDATE>), dim3((unsigned)(below / 16)), dim3(256), 0, s, ts->L + (k0 + K) * ld + k0, (long)ld,
+                           (int)K, ts->Y + k0 * NC, ts->W + (k0 + K) * NC);
+}
+
+template <int NG>
+static int ts_backward(const TriSolver *ts, hipStream_t s)
+{
+    constexpr int NC = 16 * NG;
+    const int64_t npad = ts->npad, ld = ts->ld;
+    // residual = Y (destroyed), solution -> W
+    for (int64_t p = ts->P - 1; p >= 0; --p) {
+        const int64_t k0 = p * PB, K = std::min<int64_t>(PB, npad - k0);
+        hipLaunchKernelGGL((ts_rows_kernel<NG, TS_UPPER>), dim3((unsigned)(K / 16)), dim3(256), 0, s, ts->Pz + p * (int64_t)PB * PB, (long)PB,
+                           (int)K, ts->Y + k0 * NC, ts->W + k0 * NC);
+        if (k0 > 0)
+            hipLaunchKernelGGL((ts_cols_kernel<NG>), dim3((unsigned)(k0 / 32)), dim3(512), 0, s, ts->L + k0 * ld, (long)ld, (int)K,
+                               ts->W + k0 * NC, ts->Y);
+    }
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int TriSolver::forward_begin(const double *B, int64_t ldb, int nrhs, hipStream_t s)
+{
+    if (!Pl || nrhs < 1 || nrhs > 32) { gpx_set_error("TriSolver: not prepared or nrhs out of range (%d)", nrhs); return GPX_ERR_BAD_ARG; }
+    cur_ng = nrhs > 16 ? 2 : 1;
+    const int NC = 16 * cur_ng;
+    const unsigned gp = (unsigned)(((npad >> 1) * NC + 255) / 256);
+    hipLaunchKernelGGL(ts_pack_kernel, dim3(gp), dim3(256), 0, s, B, (long)ldb, nrhs, (long)npad, NC, W);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int TriSolver::forward_step(int64_t p, hipStream_t s)
+{
+    if (!cur_ng || p < 0 || p >= P) { gpx_set_error("TriSolver::forward_step: no substitution in flight or bad panel"); return GPX_ERR_STATE; }
+    if (cur_ng == 1) ts_forward_step<1>(this, p, s);
+    else ts_forward_step<2>(this, p, s);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+int TriSolver::finish(int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof)
+{
+    if (!cur_ng) { gpx_set_error("TriSolver::finish: no substitution in flight"); return GPX_ERR_STATE; }
+    const int ng = cur_ng, NC = 16 * ng;
+    cur_ng = 0;
+    ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)npad * (double)npad * (Aout ? 1.0 : 0.0));
+    const unsigned gu = (unsigned)(((npad >> 1) * nrhs + 255) / 256);
+    if (Yout) hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)Y, (long)npad, NC, nrhs, Yout, (long)ldb);
+    if (Aout) {
+        GPX_TRY(ng == 1 ? ts_backward<1>(this, s) : ts_backward<2>(this, s));
+        hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)W, (long)npad, NC, nrhs, Aout, (long)ldb);
     }
     GPX_HIP(hipGetLastError());
     return 0;
@@ -323,21 +375,12 @@ static int ts_sweeps(const TriSolver *ts, bool backward, hipStream_t s)
 // B [nrhs][ldb] (rows) -> Yout = L^-1 B and/or Aout = L^-T L^-1 B, same layout (either may be null); nrhs <= 32
 int TriSolver::solve(const double *B, int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof)
 {
-    if (!Pl || nrhs < 1 || nrhs > 32) { gpx_set_error("TriSolver::solve: not prepared or nrhs out of range (%d)", nrhs); return GPX_ERR_BAD_ARG; }
-    const int ng = nrhs > 16 ? 2 : 1, NC = 16 * ng;
-    const double tri_bytes = 4.0 * (double)npad * (double)npad;
-    ProfScope ps(prof, s, GPX_K_TRSV, tri_bytes * (Aout ? 2.0 : 1.0));
-    const unsigned gp = (unsigned)(((npad >> 1) * NC + 255) / 256);
-    hipLaunchKernelGGL(ts_pack_kernel, dim3(gp), dim3(256), 0, s, B, (long)ldb, nrhs, (long)npad, NC, W);
-    GPX_TRY(ng == 1 ? ts_sweeps<1>(this, false, s) : ts_sweeps<2>(this, false, s));
-    const unsigned gu = (unsigned)(((npad >> 1) * nrhs + 255) / 256);
-    if (Yout) hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)Y, (long)npad, NC, nrhs, Yout, (long)ldb);
-    if (Aout) {
-        GPX_TRY(ng == 1 ? ts_sweeps<1>(this, true, s) : ts_sweeps<2>(this, true, s));
-        hipLaunchKernelGGL(ts_unpack_kernel, dim3(gu), dim3(256), 0, s, (const double *)W, (long)npad, NC, nrhs, Aout, (long)ldb);
+    GPX_TRY(forward_begin(B, ldb, nrhs, s));
+    {
+        ProfScope ps(prof, s, GPX_K_TRSV, 4.0 * (double)npad * (double)npad);
+        for (int64_t p = 0; p < P; ++p) GPX_TRY(forward_step(p, s));
     }
-    GPX_HIP(hipGetLastError());
-    return 0;
+    return finish(ldb, nrhs, Yout, Aout, s, prof);
 }
 
 // OUT = L B for up to 32 vectors stored as rows (the sampling path t = L z: skgpuppy/GaussianProcess.py:44-57): one pass over

@@ -29,6 +29,8 @@ if [ "$1" == "--" ]; then
     cd $GRAFT_REPO_ROOT
     db=$(ls $OUT/trace/*/*.db $OUT/trace/*.db 2>/dev/null | head -1)
     python tools/fit_timeline.py $db 2 detail > $OUT/timeline.txt 2>&1
-    cat $OUT/timeline.txt
+    cat $OUT/timeline.txt | head -40
+    python tools/fit_timeline.py $db 2 all ${TL_A:-18000} ${TL_B:-20000} > $OUT/timeline_all_mid.txt 2>&1
+    python tools/fit_timeline.py $db 2 all ${TL_C:-24000} 40000 > $OUT/timeline_all_tail.txt 2>&1
     rm -rf $OUT/trace
 fi

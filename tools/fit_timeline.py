@@ -28,19 +28,21 @@ def short(n):
     return n[3:20]
 
 
+def window(rows, k):
+    """launches of the k-th fit of the trace: from its ts_pack (the fit packs its targets for the forward substitution before
+    anything else) to the second ts_unpack behind it (y, alpha)"""
+    packs = [i for i, r in enumerate(rows) if "ts_pack" in r[0]]
+    i0 = packs[k]
+    unp = [i for i in range(i0, len(rows)) if "ts_unpack" in rows[i][0]]
+    i1 = unp[1] + 1
+    return rows[i0:i1], rows[i0][1]
+
+
 def main():
     rows = load(sys.argv[1])
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    seeds = [i for i, r in enumerate(rows) if "ts_seed" in r[0]]
-    i1 = seeds[k]
-    i0 = max(i for i in range(i1) if "gram_kernel" in rows[i][0])
-    # the fit assembles the first panel's columns in a launch of its own just before the rest of the Gram matrix
-    for i in range(i0 - 1, max(i0 - 6, -1), -1):
-        if "gram_kernel" in rows[i][0] and rows[i0][1] - rows[i][2] < 200000:
-            i0 = i
-    t0 = rows[i0][1]
-    win = rows[i0:i1]
-    print("fit window %.2f ms" % ((rows[i1][1] - t0) / 1e6))
+    win, t0 = window(rows, k)
+    print("fit window %.2f ms" % ((win[-1][2] - t0) / 1e6))
     qs = {}
     for r in win:
         qs.setdefault(r[3], []).append(r)
@@ -56,19 +58,14 @@ def main():
             p // 8, (grp[0][1] - t0) / 1e3, (grp[-1][2] - t0) / 1e3, (grp[-1][2] - grp[0][1]) / 1e3,
             " ".join("%4.0f" % ((g[2] - g[1]) / 1e3) for g in grp),
             ("bulk %8.1f -> %8.1f (%6.1f us, %d wgs)" % ((b[1] - t0) / 1e3, (b[2] - t0) / 1e3, (b[2] - b[1]) / 1e3, b[4])) if b else ""))
+    tail = [r for r in win if r[1] > leaves[-1][2]]
+    print("after the last leaf: %.1f us, %d launches" % ((win[-1][2] - leaves[-1][2]) / 1e3, len(tail)))
 
 
 def detail(path, k):
     """every launch of the main queue inside the fit window, with the idle time in front of it"""
     rows = load(path)
-    seeds = [i for i, r in enumerate(rows) if "ts_seed" in r[0]]
-    i1 = seeds[k]
-    i0 = max(i for i in range(i1) if "gram_kernel" in rows[i][0])
-    for i in range(i0 - 1, max(i0 - 6, -1), -1):
-        if "gram_kernel" in rows[i][0] and rows[i0][1] - rows[i][2] < 200000:
-            i0 = i
-    t0 = rows[i0][1]
-    win = rows[i0:i1]
+    win, t0 = window(rows, k)
     mainq = max(set(r[3] for r in win), key=lambda q: sum(r[2] - r[1] for r in win if r[3] == q and short(r[0]) in ("G44L", "G44", "TRAP")))
     prev = None
     print("main queue %d: start(us) dur(us) idle-before(us) kernel grid" % mainq)
@@ -80,7 +77,20 @@ def detail(path, k):
         prev = r[2]
 
 
+def everything(path, k, ta, tb):
+    """every launch of every queue that overlaps [ta, tb] us of the fit window"""
+    rows = load(path)
+    win, t0 = window(rows, k)
+    print("all queues, %.0f..%.0f us: queue start(us) dur(us) kernel grid" % (ta, tb))
+    for r in win:
+        a, b = (r[1] - t0) / 1e3, (r[2] - t0) / 1e3
+        if b >= ta and a <= tb:
+            print("  q%d %9.1f %8.1f  %-18s %d" % (r[3], a, b - a, short(r[0]), r[4] * max(1, r[5])))
+
+
 if __name__ == "__main__":
     main()
     if len(sys.argv) > 3 and sys.argv[3] == "detail":
         detail(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 5 and sys.argv[3] == "all":
+        everything(sys.argv[1], int(sys.argv[2]), float(sys.argv[4]), float(sys.argv[5]))

@@ -23,7 +23,7 @@ def main():
         P = torch.randn(OC + M, K + 16, dtype=torch.float64, device="cuda")          # rows of the panel: first OC "top" rows, then M rows
         C = torch.randn(M, ld, dtype=torch.float64, device="cuda")
         C0 = C.clone()
-        cnt = torch.zeros(4, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros(8, dtype=torch.int32, device="cuda")
         A = P[OC:]
         rc = _gpx.lib.gpx_dev_syrk_trap(p(A), K + 16, p(P), K + 16, p(C), ld, M, OC, K, -1.0, 1.0, p(cnt), st)
         torch.cuda.synchronize()
@@ -37,8 +37,9 @@ def main():
         want = torch.where(inside, ref, C0[:, :OC + M])
         err = (C[:, :OC + M] - want).abs().max().item()
         outside_ok = torch.equal(C[:, OC + M:], C0[:, OC + M:])
-        print("nt=%3d off=%d K=%4d: max err %.2e  untouched outside: %s  count %d (want %d)" % (nt, off, K, err, outside_ok, int(cnt[0]), nt * off))
-        assert err < 1e-10 and outside_ok and int(cnt[0]) == nt * off
+        counts = cnt.tolist()
+        print("nt=%3d off=%d K=%4d: max err %.2e  untouched outside: %s  counts %s (want %d per column)" % (nt, off, K, err, outside_ok, counts[:off], nt))
+        assert err < 1e-10 and outside_ok and counts[:off] == [nt] * off and counts[off:] == [0] * (8 - off)
 
 
 if __name__ == "__main__":
