@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <map>
 #include <mutex>
 #include <new>
@@ -383,6 +384,9 @@ extern "C" int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int6
 }
 
 // ---- fit ---------------------------------------------------------------------------------------
+// priorities of the fit's streams (experiment switches: GPX_MAIN_PRIO, GPX_SIDE_PRIO)
+static int main_stream_prio() { static const int v = [] { const char *e = getenv("GPX_MAIN_PRIO"); return e ? atoi(e) : 0; }(); return v; }
+static int side_stream_prio() { static const int v = [] { const char *e = getenv("GPX_SIDE_PRIO"); return e ? atoi(e) : 1; }(); return v; }
 extern "C" void gpx_free(gpx_handle *h)
 {
     if (!h) return;
@@ -395,9 +399,9 @@ extern "C" void gpx_free(gpx_handle *h)
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
-    if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); stream_release(h->s_pan, 1); }
-    if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, 1); }
-    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, 0); }
+    if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); stream_release(h->s_pan, side_stream_prio()); }
+    if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, side_stream_prio()); }
+    if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, main_stream_prio()); }
     delete h;
 }
 
@@ -416,14 +420,21 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     // y = L^-1 t rides along: the solver's diagonal squares are inverted and the forward substitution advances panel by panel on
     // the main stream while that stream would otherwise idle underneath the tail's diagonal chains (chol.hip: panel_final); only
     // the last panel's share and the backward sweep remain after the factorisation.  In the bulk-bound early panels nothing is
-    // queued (the main stream is the critical path there): the first call of the tail catches up, four panels at a time.
+    // queued (the main stream is the critical path there): the calls of the tail catch up, two to four panels at a time.
     GPX_TRY(h->tri.attach(h->L, h->npad, h->nblk, h->Dinv));
     GPX_TRY(h->tri.forward_begin(h->t, h->npad, 1, s));
     int64_t pending = 0;                                       // first outer panel the substitution has not passed yet
     bool finished = false;
     const std::function<int(int64_t, int64_t, bool)> ride = [&](int64_t p_final, int64_t slack, bool last) -> int {
-        if (!last && (!fit_ride_enabled() || slack > 5)) return 0;
-        const int64_t upto = last ? p_final + 1 : std::min<int64_t>(p_final + 1, pending + 4);
+        // slack = outer panels still to be updated: the main stream's idle time underneath the next chain grows as they run out
+        // (measured at C3: 60 us with five left, 180 / 280 / 400 / 450 / 490 us with four .. none; a panel's share costs 70-100 us)
+        static const std::array<int, 5> budget = [] {
+            std::array<int, 5> b = {1 << 20, 4, 4, 3, 2};
+            if (const char *e = getenv("GPX_RIDE_BUDGET")) (void)sscanf(e, "%d,%d,%d,%d", &b[1], &b[2], &b[3], &b[4]);   // panels per call with 1..4 panels left
+            return b;
+        }();
+        if (!last && (!fit_ride_enabled() || slack > 4)) return 0;
+        const int64_t upto = last ? p_final + 1 : std::min<int64_t>(p_final + 1, pending + budget[slack]);
         if (upto > pending) {
             GPX_TRY(h->tri.invert_squares(pending, upto, s, &h->prof));
             ProfScope ps(&h->prof, s, GPX_K_TRSV, 0.0);
@@ -466,8 +477,8 @@ static void setup_lookahead_streams(gpx_handle *h)
 {
     // The diagonal chain of the next panel runs on a second, high-priority stream underneath the main stream's work;
     // a third one carries the pipelined panel solves (chol.hip, TopPipe).
-    h->s_pan = stream_acquire(1);
-    h->s_top = stream_acquire(1);
+    h->s_pan = stream_acquire(side_stream_prio());
+    h->s_top = stream_acquire(side_stream_prio());
 }
 
 static int make_handle(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
@@ -485,7 +496,7 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
     h->nblk = h->npad / TILE;
     if (stream) h->stream = (hipStream_t)stream;
     else {
-        if (!(h->stream = stream_acquire(0))) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
+        if (!(h->stream = stream_acquire(main_stream_prio()))) { gpx_set_error("hipStreamCreate failed"); delete h; return GPX_ERR_HIP; }
         h->own_stream = true;
     }
     hipStream_t s = h->stream;

@@ -10,6 +10,7 @@
 // block AND inverts its factor in one launch, both on MFMA out of LDS, so that every triangular solve against a
 // diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -697,6 +698,8 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
     if (j > B0)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
                                -1.0, 1.0, 0, top->stream, prof, big));
+    // (Measured and dropped: the last column's update split into an early K = 768 part behind the solve two steps before and a
+    // K = 128 part after the last leaf -- one more launch per panel costs what the shorter tail gains.)
     return launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0,
                           top->stream, prof, big);
 }
@@ -952,6 +955,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         reserved = true;
         return 0;
     };
+    // GPX_DEBUG_HOST: host clock (us since the first launch) when each panel's launches are queued / its ride-along work is queued
+    auto host_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double host_t0 = getenv("GPX_DEBUG_HOST") ? host_now() : -1.0;
+    std::vector<double> host_marks;
     auto run = [&]() -> int {
         // Per outer panel p the main stream runs, in order:
         //   update of panel p+1's diagonal square (panel p's rows of that square are solved by then) -> event: the side
@@ -990,9 +997,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             }
             if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
                 GPX_TRY(reserve_now());
-                {   // the column solves stay off the reserved CUs (top_column)
+                {   // GPX_TOP_BIG=3 keeps the column solves off the reserved CUs (224-register tiles).  That was the better choice
+                    // while the trapezoid launch (208 registers then) leaked onto those CUs; with the bulk kept off them the small
+                    // tiles, which share the reserved CUs with the chain, are: fit 28.9 -> 28.1 ms
                     const char *e = getenv("GPX_TOP_BIG");
-                    for (int64_t q = p; q <= P; ++q) tops[q].big = e ? atoi(e) : 3;
+                    for (int64_t q = p; q <= P; ++q) tops[q].big = e ? atoi(e) : 0;
                 }
             }
             const int64_t K = (B1 - B0) * TILE;
@@ -1001,8 +1010,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             if (piped(p)) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
             else GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
+            // (lower 32 x 32 tiles only: nothing reads the square above its diagonal -- the bulk launches never updated it there)
+            static const int sq_lower = [] { const char *e = getenv("GPX_SQ_LOWER"); return e ? atoi(e) : 1; }();
             GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
-                                   -1.0, 1.0, 0, s, prof));
+                                   -1.0, 1.0, sq_lower, s, prof));
             GPX_HIP(hipEventRecord(ev_next[p], s));
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
@@ -1046,16 +1057,24 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }
+            // work of the caller that rides along on the main stream, behind this panel's trailing update
+            static const int hook_early = [] { const char *e = getenv("GPX_HOOK_EARLY"); return e ? atoi(e) : 1; }();
+            if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
+            if (panel_final && hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
+            if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
-            // work of the caller that rides along on the main stream (behind this panel's trailing update; queued after the chain's
-            // launches so that the chain's stream never waits for the host)
-            if (panel_final) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
+            if (panel_final && !hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
         }
         return 0;
     };
     const int rc = run();
+    if (host_t0 >= 0) {
+        fprintf(stderr, "[gpx] host enqueue marks (us): ");
+        for (double m : host_marks) fprintf(stderr, "%.0f ", m);
+        fprintf(stderr, "| all queued %.0f\n", host_now() - host_t0);
+    }
     release_blockers(s);
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits

@@ -463,6 +463,9 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
                            (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
     } else if (tiles >= SMALL_GRID_TILES || (big_tiles == 1 && !in_place) || big_tiles == 2) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently (2: also in place -- one 128-wide column tile per row block)
+    else if (lower_only && tiles <= 40.0 && K >= 512 && !ktrim) GPX_LAUNCH(1, 1);   // a 1024 x 1024 square with a long contraction (the update that
+                                                                                     // gates the factorisation's next chain): 32 x 32 tiles put two
+                                                                                     // workgroups on every CU, 64 x 64 tiles one on half of them
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE && big_tiles == 3) {   // the same 32/64-row tiles, kept off the CUs reserved for the chain (above)
         if (tiles >= SMALL_GRID_TILES / 2)
