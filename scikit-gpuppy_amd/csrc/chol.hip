@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <mutex>
 
 #include "common.h"
@@ -861,12 +862,20 @@ __global__ void wait_count_kernel(const int *ctr, int want, unsigned long long l
 // waiting kernel on one stream, the kernel that releases it launched afterwards on another.
 static bool streams_run_concurrently(hipStream_t a, hipStream_t b)
 {
-    // on the caller's own two streams (both idle here): extra streams would change which streams share a hardware queue
-    static const bool ok = [&] {
-        if (const char *e = getenv("GPX_CONCURRENT_STREAMS")) return atoi(e) != 0;
-        int *w = nullptr;
-        if (!a || !b || hipMalloc((void **)&w, 2 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
-        bool good = false;
+    // a: the stream whose kernel waits, b: the stream whose later launch releases it.  Probed once per pair of streams (they come from
+    // the library's stream cache, so the same pairs recur) on the caller's own streams, both idle here: extra streams would change
+    // which streams share a hardware queue.  Two streams of one priority class may share a hardware queue when the process has
+    // more streams than the runtime has queues for that class: the waiting kernel then sits in front of its own release.
+    if (const char *e = getenv("GPX_CONCURRENT_STREAMS")) return atoi(e) != 0;
+    if (!a || !b) return false;
+    static std::mutex mu;
+    static std::map<std::pair<hipStream_t, hipStream_t>, bool> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find({a, b});
+    if (it != seen.end()) return it->second;
+    int *w = nullptr;
+    bool good = false;
+    if (hipMalloc((void **)&w, 2 * sizeof(int)) == hipSuccess) {
         if (hipMemset(w, 0, 2 * sizeof(int)) == hipSuccess) {
             hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, a, (const int *)w, 1, 200000ull, w + 1);   // <= 2 ms
             hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, b, w, 1);
@@ -875,12 +884,12 @@ static bool streams_run_concurrently(hipStream_t a, hipStream_t b)
                 hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
                 good = (h[1] == 0);
         }
-        (void)hipGetLastError();
         (void)hipFree(w);
-        if (getenv("GPX_DEBUG")) fprintf(stderr, "[gpx] concurrent-streams probe: %d\n", (int)good);
-        return good;
-    }();
-    return ok;
+    }
+    (void)hipGetLastError();
+    if (getenv("GPX_DEBUG")) fprintf(stderr, "[gpx] concurrent-streams probe (%p waits, %p releases): %d\n", (void *)a, (void *)b, (int)good);
+    seen[{a, b}] = good;
+    return good;
 }
 
 static int reserve_cus()
@@ -927,9 +936,17 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // blockers run on a stream of their own
     // (the waiting kernel on the chain's stream, its release on the main stream: the order in which the fit first uses its streams --
     // the runtime binds a stream to a hardware queue at its first launch, and another order was measured to cost 5 ms per fit)
-    const bool concurrent = streams_run_concurrently(s_pan, s);
-    const int nres = concurrent ? reserve_cus() : 0;
-    hipStream_t s_blk = nres ? stream_acquire(0) : nullptr;
+    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    int nres = concurrent ? reserve_cus() : 0;
+    // (high priority: that class has its own hardware queues, which an application's ordinary streams do not crowd)
+    static const int blk_prio = [] { const char *e = getenv("GPX_BLK_PRIO"); return e ? atoi(e) : 1; }();
+    hipStream_t s_blk = nres ? stream_acquire(blk_prio) : nullptr;
+    if (s_blk && !(streams_run_concurrently(s_blk, s) && streams_run_concurrently(s_blk, s_pan) && (!s_top || streams_run_concurrently(s_blk, s_top)))) {
+        // the blockers would sit in front of launches their release depends on
+        stream_release(s_blk, blk_prio);
+        s_blk = nullptr;
+        nres = 0;
+    }
     int *stop_flag = info_dev + 1, *placed = info_dev + 2;
     static const int trap_env = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
     const int trap_on = trap_env && concurrent;
@@ -1078,7 +1095,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     release_blockers(s);
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
-    if (s_blk) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s_blk); stream_release(s_blk, 0); }
+    if (s_blk) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s_blk); stream_release(s_blk, blk_prio); }
     if (ev_blk) (void)hipEventDestroy(ev_blk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
