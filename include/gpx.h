@@ -175,7 +175,9 @@ enum {
     GPX_K_QUAD = 5,      /* Kinv x V pass of propagate (approx)           (bytes) */
     GPX_K_EXACT = 6,     /* Girard l_i / L_ij double sum                  (flops) */
     GPX_K_GEMM_SMALL = 7,/* the same GEMM kernel in its 64/32-row tile variants (critical-path products) */
-    GPX_K_COUNT = 8
+    GPX_K_TRSV_RIDE = 8, /* the part of the alpha solve that runs underneath the factorisation's tail (square inverses,
+                          * forward substitution of the finished panels): off the critical path, timed under contention */
+    GPX_K_COUNT = 9
 };
 /* level 0 = off, 1 = bracket only the dominant kernel (GPX_K_GEMM: 128x128-tile launches), 2 = every class.
  * Environment variable GPX_PROFILE=<level> sets the level of handles at creation (covers gpx_fit itself). */

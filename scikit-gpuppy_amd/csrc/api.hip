@@ -420,24 +420,27 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     // y = L^-1 t rides along: the solver's diagonal squares are inverted and the forward substitution advances panel by panel on
     // the main stream while that stream would otherwise idle underneath the tail's diagonal chains (chol.hip: panel_final); only
     // the last panel's share and the backward sweep remain after the factorisation.  In the bulk-bound early panels nothing is
-    // queued (the main stream is the critical path there): the calls of the tail catch up, two to four panels at a time.
+    // queued (the main stream is the critical path there): the last calls catch up.
     GPX_TRY(h->tri.attach(h->L, h->npad, h->nblk, h->Dinv));
     GPX_TRY(h->tri.forward_begin(h->t, h->npad, 1, s));
     int64_t pending = 0;                                       // first outer panel the substitution has not passed yet
     bool finished = false;
     const std::function<int(int64_t, int64_t, bool)> ride = [&](int64_t p_final, int64_t slack, bool last) -> int {
-        // slack = outer panels still to be updated: the main stream's idle time underneath the next chain grows as they run out
-        // (measured at C3: 60 us with five left, 180 / 280 / 400 / 450 / 490 us with four .. none; a panel's share costs 70-100 us)
+        // slack = outer panels still to be updated.  The main stream idles underneath the chains of the last panels, but what it runs
+        // there shares the chip with those chains (the forward updates stream the factor at HBM rate, the chain's small GEMMs slow
+        // down: chains of 0.7-0.8 ms grew to 0.9-1.1 ms when the catching-up started with four panels left, and the fit gained
+        // nothing).  So: up to eight panels per call once a single panel is left, the rest with the last calls.
         static const std::array<int, 5> budget = [] {
-            std::array<int, 5> b = {1 << 20, 4, 4, 3, 2};
+            std::array<int, 5> b = {1 << 20, 8, 0, 0, 0};
             if (const char *e = getenv("GPX_RIDE_BUDGET")) (void)sscanf(e, "%d,%d,%d,%d", &b[1], &b[2], &b[3], &b[4]);   // panels per call with 1..4 panels left
             return b;
         }();
         if (!last && (!fit_ride_enabled() || slack > 4)) return 0;
         const int64_t upto = last ? p_final + 1 : std::min<int64_t>(p_final + 1, pending + budget[slack]);
         if (upto > pending) {
-            GPX_TRY(h->tri.invert_squares(pending, upto, s, &h->prof));
-            ProfScope ps(&h->prof, s, GPX_K_TRSV, 0.0);
+            const int cls = last ? GPX_K_TRSV : GPX_K_TRSV_RIDE;   // what remains after the factorisation / what hides underneath it
+            GPX_TRY(h->tri.invert_squares(pending, upto, s, &h->prof, cls));
+            ProfScope ps(&h->prof, s, cls, 0.0);
             for (int64_t p = pending; p < upto; ++p) GPX_TRY(h->tri.forward_step(p, s));
             pending = upto;
         }

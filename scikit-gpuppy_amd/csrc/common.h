@@ -95,7 +95,7 @@ struct TriSolver {
     // prepare in pieces (the fit runs them underneath the factorisation's tail): buffers only / squares [p0, p1) of a factor whose
     // outer panels p0..p1-1 are final on stream s
     int attach(const double *L, int64_t ld, int64_t nblk, const double *Dinv);
-    int invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof);
+    int invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof, int prof_class = GPX_K_TRSV);
     // forward substitution in steps of one outer panel: begin (pack), step p (needs square p and the factor's columns of panel p),
     // finish = the rest of solve() (Yout / backward sweep / Aout)
     int forward_begin(const double *B, int64_t ldb, int nrhs, hipStream_t s);

@@ -256,10 +256,10 @@ int TriSolver::attach(const double *L_, int64_t ld_, int64_t nblk_, const double
 
 // squares [p0, p1): every launch is batched over that range only (the fit inverts the early squares underneath the factorisation's
 // tail, the last one after it)
-int TriSolver::invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof)
+int TriSolver::invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *prof, int prof_class)
 {
     if (!Pl || p0 < 0 || p1 > P || p0 >= p1) { gpx_set_error("TriSolver::invert_squares: bad range"); return GPX_ERR_BAD_ARG; }
-    ProfScope ps(prof, s, GPX_K_TRSV, 0.0);
+    ProfScope ps(prof, s, prof_class, 0.0);
     const int64_t np = p1 - p0, sp = (int64_t)PB * PB;
     double *pl = Pl + p0 * sp, *pz = Pz + p0 * sp, *tt = T + p0 * (int64_t)(PB / 2) * (PB / 2);
     hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)np), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, Pl, Pz, (int)p0);

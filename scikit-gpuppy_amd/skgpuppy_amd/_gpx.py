@@ -14,9 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GPX_LIB", os.path.join(_HERE, "libgpx.so"))   # GPX_LIB: diagnostic builds only
 
 GPX_ERR_BAD_ARG, GPX_ERR_HIP, GPX_ERR_NO_DEVICE, GPX_ERR_STATE = -1, -2, -3, -4
-K_GRAM, K_GEMM, K_POTRF_LEAF, K_TRSV, K_REDUCE, K_QUAD, K_EXACT, K_GEMM_SMALL = range(8)
+K_GRAM, K_GEMM, K_POTRF_LEAF, K_TRSV, K_REDUCE, K_QUAD, K_EXACT, K_GEMM_SMALL, K_TRSV_RIDE = range(9)
 KERNEL_CLASS_NAMES = ["gram", "gemm_f64_mfma", "potrf_leaf", "trsv", "predict_reduce", "approx_quad", "exact_sum",
-                      "gemm_f64_mfma_small_tiles"]
+                      "gemm_f64_mfma_small_tiles", "trsv_under_factorisation"]
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
