@@ -174,6 +174,7 @@ enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B
 struct GemmBatch { int nq; long sp, sq; int tri; };
 int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
                            GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);
+int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s);
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof, int exclusive = 0);
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
             bx = rem / rows;
         }
     }
-    if (ba.nq) {
+    if (ba.nq && !LOWER) {
         // batched launches with a triangular operand: tile lengths depend on by (or bx), and the dispatcher hands tile
         // (by, bx) of every problem to the same CU / XCD -- rotate the tile coordinates with the problem index so that
         // every CU sees the whole mix of lengths
@@ -364,6 +364,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const d
 // C[M, off_cols + M] (lower trapezoid by 128-tiles, see the kernel) = alpha A B^T + beta C with A [M, K], B [off_cols + M, K]; sig_dev[c]
 // (off_cols / 128 ints, zero before the launch) counts the finished tiles of tile column c of the first off_cols columns: M / 128 each in the end.
 // Returns GPX_ERR_STATE when the shape does not suit this launch (the caller then issues the two launches it replaces).
+// parts[c] (lower 128 x 128 tiles of an [m, m] matrix, c = 0 .. nchunks-1) = alpha W_c W_c^T with W_c = W[:, c * kchunk : (c + 1) * kchunk):
+// the split-K form of a tall-skinny SYRK (contraction >> m) as ONE launch of nchunks x m/128 (m/128 + 1) / 2 tiles -- the caller sums
+// the parts.  (Chunks as launches of their own on several streams share the runtime's few hardware queues and run two or four at a
+// time; one launch lets the caller pick nchunks so that the tiles fill whole rounds of the chip's 512 places.)
+int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s)
+{
+    if (m % TILE || kchunk % GEMM_BK || kchunk <= 0 || nchunks < 1 || (ldw & 1) || ((uintptr_t)W & 15) || alpha == 0.0) {
+        gpx_set_error("launch_syrk_lower_splitk: shape/alignment not supported");
+        return GPX_ERR_BAD_ARG;
+    }
+    const unsigned nt = (unsigned)(m / TILE);
+    const GemmBatch bab = {nchunks, 0, (long)kchunk, 0}, bc = {nchunks, 0, (long)(m * m), 0};
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, true>), dim3(nt * (nt + 1) / 2, 1, (unsigned)nchunks), dim3(256), 0, s, W, (long)ldw, W, (long)ldw,
+                       parts, (long)m, (int)kchunk, alpha, 0.0, 0, 0, (int)nt, bab, bab, bc);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
                             double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof)
 {

@@ -38,18 +38,21 @@ struct gpx_spgp {
     double *ma = nullptr, *mb = nullptr, *mzero = nullptr, *beta = nullptr, *mscr = nullptr;   // [mpad]
     double *outd = nullptr;  // [8] scalar results
     int *info = nullptr;
-    static constexpr int SPLIT = 8;                 // K-chunks of the tall-skinny product W^T W (K = N)
-    hipStream_t split_stream[SPLIT] = {};
-    hipEvent_t split_ev[SPLIT + 1] = {};
-    double *split_buf = nullptr;                    // [SPLIT - 1][mpad, mpad] partial products
+    int split = 0;                                  // K-chunks of the tall-skinny product W^T W (K = N), 0: one plain launch
+    double *split_buf = nullptr;                    // [split][mpad, mpad] partial products
 };
 
-// out[i] += sum_s part[s][i]   (lower tiles matter only; summing everything keeps the kernel trivial)
-__global__ __launch_bounds__(256) void add_partials_kernel(double *__restrict__ out, const double *__restrict__ part, long elems, int nparts)
+// out[i] = beta out[i] + sum_s part[s][i]   (lower tiles matter only; summing everything keeps the kernel trivial)
+__global__ __launch_bounds__(256) void add_partials_kernel(double *__restrict__ out, const double *__restrict__ part, long elems, int nparts, double beta)
 {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
     if (i >= elems) return;
-    v2d acc = *reinterpret_cast<const v2d *>(out + i);
+    v2d acc = (v2d){0.0, 0.0};
+    if (beta != 0.0) {
+        acc = *reinterpret_cast<const v2d *>(out + i);
+        acc.x *= beta;
+        acc.y *= beta;
+    }
     for (int s = 0; s < nparts; ++s) {
         const v2d p = *reinterpret_cast<const v2d *>(part + (long)s * elems + i);
         acc.x += p.x;
@@ -58,32 +61,38 @@ __global__ __launch_bounds__(256) void add_partials_kernel(double *__restrict__ 
     *reinterpret_cast<v2d *>(out + i) = acc;
 }
 
+// number of K-chunks for an [m, m] lower SYRK with contraction np: a divisor of np / 128 (equal chunks of whole tiles, at least 2048
+// long) whose chunk x tile count fills whole rounds of the chip's 512 workgroup places best; 0 = do not split
+static int spgp_pick_split(int64_t mp, int64_t np)
+{
+    if (np < 16384) return 0;
+    const int64_t T = (mp / TILE) * (mp / TILE + 1) / 2, nb = np / TILE;
+    int best = 0;
+    double best_eff = (double)T / 512.0 / std::ceil((double)T / 512.0) * 0.999;   // unsplit
+    for (int64_t d = 2; d <= 64 && d <= nb; ++d) {
+        if (nb % d || np / d < 2048 || d * mp * mp * 8 > ((int64_t)4 << 30)) continue;
+        const double rounds = (double)(T * d) / 512.0, eff = rounds / std::ceil(rounds);
+        if (eff >= 0.94) return (int)d;   // good enough: fewer parts to sum (C5: 16 / 32 / 64 chunks measured 41.7 / 41.1 / 41.9 ms per fit)
+        if (eff > best_eff + 1e-9) { best_eff = eff; best = (int)d; }
+    }
+    return best;
+}
+
 // C (lower tiles) <- beta C + alpha W W^T for a [mpad, npad] row-major W: the contraction runs over N = 262144 at BASELINE
-// config 5 while C has only 136 lower 128x128 tiles, so it is split into K-chunks that run concurrently on their own
-// streams (chunk 0 accumulates into C, the others into scratch) and are summed afterwards.
+// config 5 while C has only 136 lower 128x128 tiles, so it is split into K-chunks -- ONE launch over all chunks into scratch
+// (gemm.hip: launch_syrk_lower_splitk), summed by one pass.  Round 2 ran eight chunks as eight launches on eight streams: those
+// share four hardware queues, and 8 x 136 tiles are 2.1 rounds of the chip anyway; now the chunk count is chosen so that the tiles
+// fill whole rounds (C5: 64 chunks of 4096 = 17 rounds exactly).
 static int spgp_wtw(gpx_spgp *h, const double *W, double *C, double beta, double alpha = 1.0)
 {
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad;
-    int64_t chunk = round_up((np + gpx_spgp::SPLIT - 1) / gpx_spgp::SPLIT, TILE);
-    const int nchunks = (int)((np + chunk - 1) / chunk);
-    if (np < 16384 || nchunks < 2 || !h->split_buf)
+    if (h->split < 2 || !h->split_buf)
         return launch_gemm_nt(W, np, W, np, C, mp, mp, mp, np, alpha, beta, 1, s, nullptr);
-    GPX_HIP(hipEventRecord(h->split_ev[gpx_spgp::SPLIT], s));
-    for (int c = 0; c < nchunks; ++c) {
-        const int64_t k0 = c * chunk, kc = std::min<int64_t>(chunk, np - k0);
-        hipStream_t sc = (c == 0) ? s : h->split_stream[c];
-        if (c > 0) GPX_HIP(hipStreamWaitEvent(sc, h->split_ev[gpx_spgp::SPLIT], 0));
-        double *Cc = (c == 0) ? C : h->split_buf + (int64_t)(c - 1) * mp * mp;
-        GPX_TRY(launch_gemm_nt(W + k0, np, W + k0, np, Cc, mp, mp, mp, kc, alpha, (c == 0) ? beta : 0.0, 1, sc, nullptr, 1));
-        if (c > 0) {
-            GPX_HIP(hipEventRecord(h->split_ev[c], sc));
-            GPX_HIP(hipStreamWaitEvent(s, h->split_ev[c], 0));
-        }
-    }
+    GPX_TRY(launch_syrk_lower_splitk(W, np, h->split_buf, mp, np / h->split, h->split, alpha, s));
     // the partial buffers' strictly-upper tiles are never written: they were zeroed once at allocation and stay zero
     const long elems = (long)mp * mp;
-    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, s, C, (const double *)h->split_buf, elems, nchunks - 1);
+    hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, s, C, (const double *)h->split_buf, elems, h->split, beta);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -184,10 +193,6 @@ extern "C" void gpx_spgp_free(gpx_spgp *h)
                     h->ilam, h->va, h->vb, h->vc, h->ma, h->mb, h->mzero, h->beta, h->mscr, h->outd};
     for (void *p : bufs) dfree(p);
     if (h->info) dfree(h->info);
-    for (int c = 1; c < gpx_spgp::SPLIT; ++c)
-        if (h->split_stream[c]) { (void)hipStreamSynchronize(h->split_stream[c]); stream_release(h->split_stream[c], 0); }
-    for (int c = 0; c <= gpx_spgp::SPLIT; ++c)
-        if (h->split_ev[c]) (void)hipEventDestroy(h->split_ev[c]);
     dfree(h->split_buf);
     if (h->stream) stream_release(h->stream, 0);
     delete h;
@@ -263,12 +268,14 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
         GPX_TRY(dalloc(&ib, 1));
         h->info = reinterpret_cast<int *>(ib);
     }
-    if (np >= 16384) {   // split-K machinery of spgp_wtw
-        GPX_TRY(dalloc(&h->split_buf, (int64_t)(gpx_spgp::SPLIT - 1) * mp * mp));
-        GPX_HIP(hipMemsetAsync(h->split_buf, 0, sizeof(double) * (gpx_spgp::SPLIT - 1) * mp * mp, s));
-        for (int c = 1; c < gpx_spgp::SPLIT; ++c)
-            if (!(h->split_stream[c] = stream_acquire(0))) { gpx_set_error("stream creation failed"); return GPX_ERR_HIP; }
-        for (int c = 0; c <= gpx_spgp::SPLIT; ++c) GPX_HIP(hipEventCreateWithFlags(&h->split_ev[c], hipEventDisableTiming));
+    {   // split-K scratch of spgp_wtw (GPX_SPGP_SPLIT overrides the chunk count; it must divide npad / 128)
+        const char *e = getenv("GPX_SPGP_SPLIT");
+        h->split = e ? atoi(e) : spgp_pick_split(mp, np);
+        if (h->split >= 2 && (np / TILE) % h->split == 0) {
+            GPX_TRY(dalloc(&h->split_buf, (int64_t)h->split * mp * mp));
+            GPX_HIP(hipMemsetAsync(h->split_buf, 0, sizeof(double) * h->split * mp * mp, s));
+        } else
+            h->split = 0;
     }
     // raw inputs are staged through Z / LB (both overwritten below)
     GPX_HIP(hipMemcpyAsync(h->Z, x, sizeof(double) * n * d, hipMemcpyDefault, s));
