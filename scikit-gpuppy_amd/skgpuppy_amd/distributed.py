@@ -657,9 +657,12 @@ def bench_main(args):
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    if os.environ.get("GPX_BENCH_WATCHDOG"):       # diagnostic: Python stack of a stuck run after that many seconds
+    # a stuck collective must not hold the node: after GPX_BENCH_WATCHDOG seconds (default 1200, 0 = never) every rank writes its
+    # Python stacks to stderr and exits non-zero
+    watchdog = int(os.environ.get("GPX_BENCH_WATCHDOG", "1200"))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["GPX_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
