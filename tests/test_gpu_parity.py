@@ -651,6 +651,20 @@ def test_nll_and_gradient_golden(case):
         np.testing.assert_allclose(got, refg, rtol=1e-6 * k, atol=1e-6 * k * max(1.0, np.abs(refg).max()))
 
 
+def test_nll_and_gradient_against_oracle_at_4096():
+    """f1 beyond the golden sizes (the largest fixture has N = 1000): one likelihood + gradient evaluation at N = 4096, d = 8 -- four
+    outer panels of the look-ahead factorisation, K^-1 by the structured recursion, the fused gradient pass -- against the oracle's
+    LU / 2 + d derivative Grams (skgpuppy/Covariance.py:197-282)."""
+    N, d = 4096, 8
+    x, t, _xs, theta = _recipe(N, d, 8)
+    tc = t - t.mean()
+    cov = sk.GaussianCovariance()
+    th = theta + 0.05 * np.arange(d + 2)                 # away from the recipe's generating parameters
+    ref, refg = orc.nll(x, tc, th), orc.nll_grad(x, tc, th)
+    assert cov._negativeloglikelihood(x, tc, th) == pytest.approx(ref, rel=1e-8, abs=1e-6)
+    np.testing.assert_allclose(cov._d_nll_d_theta(x, tc, th), refg, rtol=1e-6, atol=1e-6 * max(1.0, np.abs(refg).max()))
+
+
 def test_gradient_matches_finite_differences():
     """the reference's own check (skgpuppy/tests/tests.py:611-624, tolerance 5e-1 there)."""
     g = load_golden("n203_d3")
