@@ -205,11 +205,6 @@ int gpx_dev_gram_scaled(const double *xiw_dev, int64_t n1, const double *xjw_dev
 /* C = alpha * A B^T + beta * C  with A[M,K], B[N,K]; lower_only skips tiles above the diagonal */
 int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                     int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream);
-/* the same product on the small-footprint ("sliver") kernel: at most 16 KB of LDS and 64 VGPRs per workgroup, so that it is
- * placed at once on a chip that a bulk launch saturates (the latency-bound steps of the factorisation's diagonal chain).
- * N == GPX_TILE: 32 x 128 tiles, in-place products (C == A or C == B) allowed; otherwise M, N multiples of 64.  K % 4 == 0. */
-int gpx_dev_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
-                           int64_t M, int64_t N, int64_t K, double alpha, double beta, void *stream);
 /* the trailing update of a factorisation panel as ONE launch: C [M, off_cols + M] = alpha A B^T + beta C with A [M, K], B [off_cols + M, K];
  * by 128-tiles, tile row r holds the first off_cols / 128 columns in full and then the lower triangle (r + 1 tiles).  The tiles of the
  * first off_cols columns are computed first and counted per tile column in count_dev[0 .. off_cols / 128) (device ints, zero before the

@@ -239,6 +239,7 @@ extern "C" int gpx_pool_trim(void)
     for (auto &kv : g_stream_cache)
         for (hipStream_t st : kv.second) (void)hipStreamDestroy(st);
     g_stream_cache.clear();
+    chol_concurrency_forget();   // verdicts are keyed by stream: a new stream at a recycled address may sit on another hardware queue
     g_pool_cached_bytes = 0;
     return 0;
 }
@@ -412,10 +413,11 @@ static int fit_ride_enabled()
     return v;
 }
 
+// info_host[0] = potrf status, info_host[1] = stall word (common.h, chol_factor)
 static int factor_once(gpx_handle *h, double add_diag, int *info_host)
 {
     hipStream_t s = h->stream;
-    GPX_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int), s));
+    GPX_HIP(hipMemsetAsync(h->info_dev, 0, 2 * sizeof(int), s));
     const int64_t c1 = CHOL_PANEL_COLS;
     // y = L^-1 t rides along: the solver's diagonal squares are inverted and the forward substitution advances panel by panel on
     // the main stream while that stream would otherwise idle underneath the tail's diagonal chains (chol.hip: panel_final); only
@@ -467,7 +469,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
         GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, &rest, &ride));
     }
     GPX_TRY(ride(h->tri.P - 1, 0, true));                      // whatever the factorisation's schedule left over
-    GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;
 }
@@ -525,26 +527,45 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
         return fail(rc);
     {
         double *ib = nullptr;
-        if ((rc = dalloc(&ib, h->nblk + 2))) return fail(rc);   // (2 + 2 nblk) ints
+        if ((rc = dalloc(&ib, h->nblk + 8))) return fail(rc);   // (16 + 2 nblk) ints: status, stall, blocker words, per-panel counters
         h->info_dev = reinterpret_cast<int *>(ib);
     }
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
-    FIT_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int) * (2 + 2 * h->nblk), s));
+    FIT_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int) * (16 + 2 * h->nblk), s));
     FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
     FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
     FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
     FIT_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * h->npad, s));
     FIT_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
     FIT_HIP(hipStreamSynchronize(s));   // sw is a stack buffer: its copy must be complete before any return path
+    if (!ext) chol_probe_streams(s, h->s_pan, h->s_top);   // while every stream of the fit is idle (cached per pair of streams)
     if ((rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
 
     if (!ext) {
+        // A stalled hand-off (an in-kernel wait of the look-ahead schedule expired: streams that were probed as concurrent no longer
+        // are) is not a property of K: that factor is discarded and the fit repeated ONCE on the plain schedule -- no kernel waits
+        // for a kernel of another stream there --, never with jitter.
+        auto factor = [&](double add_diag, int *info) -> int {
+            int st[2] = {0, 0};
+            GPX_TRY(factor_once(h, add_diag, st));
+            if (st[1]) {
+                if (getenv("GPX_DEBUG")) fprintf(stderr, "[gpx] factorisation hand-off stalled: refit on the plain schedule\n");
+                chol_concurrency_forget();
+                chol_force_plain_schedule(true);
+                const int rc2 = factor_once(h, add_diag, st);
+                chol_force_plain_schedule(false);
+                GPX_TRY(rc2);
+                if (st[1]) { gpx_set_error("factorisation stalled on the plain schedule as well"); return GPX_ERR_STATE; }
+            }
+            *info = st[0];
+            return 0;
+        };
         int info = 0;
-        if ((rc = factor_once(h, h->vt, &info))) return fail(rc);
+        if ((rc = factor(h->vt, &info))) return fail(rc);
         if (info > 0) {
             // reference fallback: cholesky(K + 1e-5 I)   (skgpuppy/Covariance.py:180-185)
             h->jitter = 1e-5;
-            if ((rc = factor_once(h, h->vt + h->jitter, &info))) return fail(rc);
+            if ((rc = factor(h->vt + h->jitter, &info))) return fail(rc);
             if (info > 0) {
                 gpx_set_error("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter", info);
                 return fail(info);
@@ -1281,7 +1302,7 @@ extern "C" int gpx_nll_grad(gpx_handle *h, double *grad_out)
     GPX_HIP(e);
     std::vector<double> g(d + 2);
     g[0] = 0.5 * o[0];                                   // dK/dtheta_0 = Kf            (Covariance.py:633-639)
-    g[1] = 0.5 * (h->vt + h->jitter * 0.0) * o[dm + 1];  // dK/dtheta_1 = vt I          (Covariance.py:505-510)
+    g[1] = 0.5 * h->vt * o[dm + 1];                      // dK/dtheta_1 = vt I          (Covariance.py:505-510)
     for (int k = 0; k < d; ++k) g[2 + k] = -0.25 * o[1 + k];   // dK/dtheta_{2+k} = -1/2 Kf w_k dx_k^2 (:643-657); w_k is in the scaled inputs
     GPX_HIP(hipMemcpy(grad_out, g.data(), sizeof(double) * (d + 2), hipMemcpyDefault));
     return 0;

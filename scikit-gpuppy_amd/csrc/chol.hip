@@ -34,30 +34,6 @@ __device__ __forceinline__ double fast_rsqrt(double d)
 constexpr int XB = 16 * 17;                                  // doubles per packed block
 __device__ __forceinline__ int xblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * XB; }
 
-// ------------------------------------------------------------------------------------------------
-// Leaf: factor + inverse of a 128x128 diagonal block with all O(128^3) work on MFMA (a register-resident VALU
-// formulation queues behind the bulk GEMM's fp64 MFMAs whenever the leaf shares its SIMDs with a bulk workgroup --
-// it always does under the look-ahead schedule -- and ran 2-7x slower).  The block lives in LDS as 36 packed 16x16 blocks.  Per 16-column panel, wave 0
-// eliminates the AUGMENTED 32x16 panel [A_d; I] in registers -- lane (i = lane&15, q = lane>>4) holds columns
-// q, q+4, q+8, q+12 of row i of both halves, multipliers travel by ds_bpermute -- which yields L_d and, from the
-// identity rows, inv(L_d)^T without a separate triangular inversion.  All four waves then apply
-// L_ib = A_ib inv(L_d)^T and the trailing update as 16x16x4 MFMAs.  The inverse is finished in place (each L21 block
-// is consumed exactly once by the recursive doubling), so no operand leaves LDS between load and store.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double bperm_f64(double v, int byte_index)
-{
-    const int lo = __builtin_amdgcn_ds_bpermute(byte_index, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(byte_index, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-
 // In-kernel stamps of the leaf's phases: only in the builder-side probe build (tools/native/probe_leafk.hip defines the macro
 // and includes this file); the library build contains none of it.
 #ifdef GPX_LEAF_STAMPS
@@ -177,151 +153,9 @@ __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, do
 #undef bad_s
 }
 
-// X: packed lower blocks A -> L -> inverse (in place); Gs: inv(L_d)^T of the current panel.  The inverses of the eight
-// diagonal 16-blocks wait in their final place in `dinv` (global) until the factor has left the LDS: the leaf's footprint
-// stays at 80 KB, which fits next to one bulk GEMM workgroup (64 KB) on a CU with room to spare.
-__device__ __forceinline__ void leaf_mfma_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
-                                               double *X, double *Gs, int *bad_sp)
-{
-#define bad_s (*bad_sp)
-    const int t = threadIdx.x;
-    const int wave = t >> 6, lane = t & 63;
-    const int fr = lane & 15, fq = lane >> 4;
-
-    if (t == 0) bad_s = 0;
-    {   // thread t carries element (t>>4, t&15) of every 16x16 block: 36 independent loads in flight, then 36 LDS stores
-        const int r = t >> 4, c = t & 15;
-        double v[36];
-#pragma unroll
-        for (int bi = 0; bi < 8; ++bi)
-#pragma unroll
-            for (int bj = 0; bj <= bi; ++bj) v[bi * (bi + 1) / 2 + bj] = A[(long)(16 * bi + r) * ld + 16 * bj + c];
-#pragma unroll
-        for (int b = 0; b < 36; ++b) X[b * XB + r * 17 + c] = v[b];
-    }
-    __syncthreads();
-
-#pragma unroll 1
-    for (int jb = 0; jb < 8; ++jb) {
-        if (wave == 0) {
-            double *Db = &X[xblk(jb, jb)];
-            double e[4], g[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                e[m] = Db[fr * 17 + fq + 4 * m];
-                g[m] = (fr == fq + 4 * m) ? 1.0 : 0.0;
-            }
-            int bad = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int mj = j >> 2, qj = j & 3;
-                double djj = readlane_f64(e[mj], qj * 16 + j);
-                if (!(djj > 0.0)) {
-                    if (bad == 0) bad = col_offset + 16 * jb + j + 1;
-                    djj = 1.0;
-                }
-                const double rinv = fast_rsqrt(djj);
-                const int src_row = (qj * 16 + fr) * 4;                       // lane (i, q_j): this row's entry of column j
-                const double ecol = e[mj], gcol = g[mj];                       // column j before it is scaled below
-                // all exchanges first (they do not depend on the pivot's reciprocal square root)
-                const double pl = bperm_f64(ecol, src_row);
-                const double pg = bperm_f64(gcol, src_row);
-                double pc[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) pc[m] = (m >= mj) ? bperm_f64(ecol, (qj * 16 + fq + 4 * m) * 4) : 0.0;   // A[c][j], c = fq + 4m
-                const double li = pl * rinv, lg = pg * rinv;                   // row j itself: d_jj * rinv = L_jj
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    if (m < mj) continue;                                       // columns left of the pivot are final
-                    const double lc = pc[m] * rinv;                             // L[c][j]
-                    const double ne = fma(-li, lc, e[m]), ng = fma(-lg, lc, g[m]);
-                    if (m > mj) {
-                        e[m] = ne;
-                        g[m] = ng;
-                    } else {                                                    // the pivot's own column group: select per lane
-                        e[m] = (fq > qj) ? ne : ((fq == qj) ? li : e[m]);
-                        g[m] = (fq > qj) ? ng : ((fq == qj) ? lg : g[m]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int c = fq + 4 * m;
-                Db[fr * 17 + c] = (c <= fr) ? e[m] : 0.0;
-                const double gv = (c >= fr) ? g[m] : 0.0;                        // inv(L_d)^T[fr][c] = inv(L_d)[c][fr]
-                Gs[fr * 17 + c] = gv;
-                dinv[(16 * jb + c) * TILE + 16 * jb + fr] = gv;
-            }
-            if (bad && lane == 0 && bad_s == 0) bad_s = bad;
-        }
-        __syncthreads();
-        // ---- panel: L[ib][jb] = A[ib][jb] inv(L_d)^T ----
-        {
-            const double *Bb = &Gs[fq * 17 + fr];                  // B[k = 4kk + fq][col fr]
-            v4d res[2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int ib = jb + 1 + wave + 4 * q;
-                res[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-                if (ib < 8) {
-                    const double *Ab = &X[xblk(ib, jb) + fr * 17 + fq];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        res[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ab[4 * kk], Bb[4 * kk * 17], res[q], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int ib = jb + 1 + wave + 4 * q;
-                if (ib < 8) {
-                    double *Ob = &X[xblk(ib, jb)];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Ob[(fq + 4 * r) * 17 + fr] = res[q][r];
-                }
-            }
-        }
-        __syncthreads();
-        // ---- trailing update: A[ib][kb] -= L[ib][jb] L[kb][jb]^T, jb < kb <= ib ----
-        {
-            const int nb = 7 - jb;
-            const int ntask = nb * (nb + 1) / 2;
-            for (int task = wave; task < ntask; task += 4) {
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= task) ++ii;           // row within the trailing triangle
-                const int kk0 = task - ii * (ii + 1) / 2;
-                const int ib = jb + 1 + ii, kb = jb + 1 + kk0;
-                double *Cb = &X[xblk(ib, kb)];
-                const double *La = &X[xblk(ib, jb) + fr * 17 + fq];
-                const double *Lb = &X[xblk(kb, jb) + fr * 17 + fq];
-                v4d acc;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = Cb[(fq + 4 * r) * 17 + fr];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-La[4 * kk], Lb[4 * kk], acc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Cb[(fq + 4 * r) * 17 + fr] = acc[r];
-            }
-        }
-        __syncthreads();
-    }
-
-    leaf_finish(A, ld, dinv, diag_out, info, X, bad_sp);
-#undef bad_s
-}
-
-__global__ __launch_bounds__(256) void potrf_trtri128_mfma_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
-                                                                 int col_offset)
-{
-    __shared__ __attribute__((aligned(16))) double X[36 * XB];
-    __shared__ __attribute__((aligned(16))) double Gs[XB];
-    __shared__ int bad_s;
-    __builtin_amdgcn_s_setprio(3);
-    leaf_mfma_body(A, ld, dinv, diag_out, info, col_offset, X, Gs, &bad_s);
-}
-
-
 // ------------------------------------------------------------------------------------------------
-// Leaf, second formulation (the default): the 16-column panel step is a row-parallel LDL^T elimination with no
+// Leaf: factor + inverse of a 128x128 diagonal block in one launch, the block held in LDS as 36 packed 16x16 blocks, all
+// O(128^3) work on MFMA.  The 16-column panel step is a row-parallel LDL^T elimination with no
 // cross-lane traffic through LDS.  Lane = column c of the panel (16 lanes = one DPP row), registers = rows: a group of
 // 16 lanes holds the symmetric diagonal block (16 registers) plus one row of the appended identity and one row of each
 // block below (7 registers), the 16 groups of the workgroup covering all 128 rows.  Pivot j: the pivot and each row's
@@ -525,12 +359,6 @@ static int leaf_prio()
     static const int v = [] { const char *e = getenv("GPX_LEAF_PRIO"); return e ? atoi(e) : 1; }();
     return v;
 }
-static int leaf_variant()
-{
-    static const int v = [] { const char *e = getenv("GPX_LEAF"); return (e && e[0] == 'o') ? 0 : 1; }();   // GPX_LEAF=old: the bpermute formulation
-    return v;
-}
-
 // exclusive: the launch asks for 52 KB of dynamic LDS on top of the kernel's 78 KB, so that no workgroup of any GEMM variant
 // (>= 32 KB) can join it on its CU -- next to a bulk wave on every SIMD the leaf runs 3x slower.  Only where an empty CU is at
 // hand: the first leaf of a panel (the main stream has just drained) and every leaf while CUs are reserved for the chain.
@@ -549,11 +377,8 @@ int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int
                       hipStream_t s, Profiler *prof, int exclusive)
 {
     ProfScope ps(prof, s, GPX_K_POTRF_LEAF, (double)TILE * TILE * TILE);   // n^3/3 (potrf) + 2n^3/3 (inverse)
-    if (leaf_variant())
-        hipLaunchKernelGGL(potrf_trtri128_elim_kernel, dim3(1), dim3(256), (exclusive && leaf_exclusive_enabled()) ? 52 * 1024 : 0, s, A, (long)ld, dinv,
-                           diag_out, info_dev, col_offset, leaf_prio());
-    else
-        hipLaunchKernelGGL(potrf_trtri128_mfma_kernel, dim3(1), dim3(256), 0, s, A, (long)ld, dinv, diag_out, info_dev, col_offset);
+    hipLaunchKernelGGL(potrf_trtri128_elim_kernel, dim3(1), dim3(256), (exclusive && leaf_exclusive_enabled()) ? 52 * 1024 : 0, s, A, (long)ld, dinv,
+                       diag_out, info_dev, col_offset, leaf_prio());
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -611,7 +436,7 @@ static int trtri_upper_rec(double *Z, int64_t ldz, const double *L, int64_t ldl,
     // Z[0:cm, c0:cm) is upper triangular below row c0 (Z[r][k] = 0 for k < r): row tiles past c0 start their k loop at
     // their own first row (ktrim shift = c0 * 128) -- at the top level that halves the launch
     GPX_TRY(launch_gemm_nt(Z + c0 * TILE, ldz, L + (cm * TILE) * ldl + c0 * TILE, ldl, Z + cm * TILE, ldz, cm * TILE,
-                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof, 0, (int)(c0 * TILE) + 1));
+                           (c1 - cm) * TILE, h * TILE, -1.0, 1.0, 0, s, prof, (int)(c0 * TILE) + 1));
     return trtri_upper_rec(Z, ldz, L, ldl, Dinv, cm, c1, s, prof);
 }
 
@@ -633,7 +458,7 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
     // ONE lower-only launch whose tile (by, bx) contracts over k >= 128 by only (Z is upper triangular): N^3/3 flop with
     // tiles of length 128 .. N dealt longest-first to whichever workgroup slot frees up (row strips of 1024 with a common
     // k range per strip ran at 49 TFLOP/s: the first strips have few tiles, the last ones short k)
-    GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 0, 1));
+    GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 1));
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }
 
@@ -674,16 +499,23 @@ static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 // Optional pipelining of the "top slice": the rows [r0, r1) below the square (the next panel's diagonal-square rows) are
 // solved against the square's triangle column by column on a second stream, each column as soon as the chain step that
 // produces its diagonal-block inverse has finished -- instead of one recursive TRSM after the whole chain.
-__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *info);
+__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *stall);
+
+// time limit of the in-kernel waits (GPX_WAIT_LIMIT_MS, default 5000): generous -- it only ever expires when streams that were
+// probed as concurrent stop being so
+static unsigned long long wait_limit_ticks()
+{
+    static const unsigned long long v = [] { const char *e = getenv("GPX_WAIT_LIMIT_MS"); const double ms = e ? atof(e) : 5000.0; return (unsigned long long)((ms > 0.01 ? ms : 0.01) * 1e5); }();
+    return v;   // s_memrealtime ticks at 100 MHz
+}
 
 struct TopPipe {
     hipStream_t stream = nullptr;
     int64_t r0 = 0, r1 = 0;                 // block rows of the slice
     std::vector<hipEvent_t> *events = nullptr;   // owned by the caller, destroyed after the final synchronisation
-    int big = 0;                            // 3: tiles with the bulk kernel's register footprint (see the CU reservation in chol_factor)
     const int *colsig = nullptr;            // column c of the slice may be read once colsig[c] has reached colwant (the trapezoid launch's
     int colwant = 0;                        // per-column counters); null: the stream is ordered behind the update some other way
-    int *info = nullptr;
+    int *stall = nullptr;                   // the factorisation's stall word (an expired wait sets it)
 };
 
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
@@ -691,18 +523,22 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
 {
     double *Zt = L + (top->r0 * TILE) * ld;
     const int64_t M = (top->r1 - top->r0) * TILE;
-    // with CUs reserved for the chain these launches take the bulk kernel's 128 x 128 tiles (224 VGPRs): they must not
-    // settle on the reserved CUs, where the chain's own small kernels would then queue behind them
-    const int big = top->big;
-    if (top->colsig)   // a one-thread kernel in front of the column's solve (on the device it runs next to the trapezoid launch)
-        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + (j - B0), top->colwant, 500000000ull, top->info);   // <= 5 s
+    if (top->colsig) {   // a one-thread kernel in front of the column's solve (on the device it runs next to the trapezoid launch)
+        static const bool force_stall = getenv("GPX_TEST_FORCE_STALL") != nullptr;   // test hook: the first wait of the process expires at once
+        static bool forced = false;
+        const bool force = force_stall && !forced;
+        forced = forced || force;
+        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + (j - B0), force ? 0x7fffffff : top->colwant,
+                           force ? 1000ull : wait_limit_ticks(), top->stall);
+        GPX_HIP(hipGetLastError());
+    }
     if (j > B0)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
-                               -1.0, 1.0, 0, top->stream, prof, big));
+                               -1.0, 1.0, 0, top->stream, prof));
     // (Measured and dropped: the last column's update split into an early K = 768 part behind the solve two steps before and a
     // K = 128 part after the last leaf -- one more launch per panel costs what the shorter tail gains.)
     return launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0,
-                          top->stream, prof, big);
+                          top->stream, prof);
 }
 
 static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int64_t j0, int64_t j1, double *Dinv,
@@ -808,7 +644,7 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
 
 
 // ------------------------------------------------------------------------------------------------
-// CU reservation for the diagonal chain.  Measured (tools/native/probe_slot.hip, probe_leafk.hip, probe_sliver.py): while a bulk
+// CU reservation for the diagonal chain.  Measured (tools/native/probe_slot.hip, probe_leafk.hip): while a bulk
 // launch saturates the chip (two workgroups per CU, 224 VGPRs per wave), a small kernel of the chain waits 40-130 us for a
 // retiring bulk workgroup's place -- equal-length tiles retire in bursts -- and then runs 3x (next to one bulk wave per SIMD)
 // to 10x (next to two) slower than alone; kernels small enough to be placed at once (<= 64 VGPRs, <= 16 KB of LDS) pay the
@@ -842,14 +678,15 @@ __global__ void wait_placed_kernel(const int *placed, int want, unsigned long lo
 }
 
 // holds its stream until the producer launch has counted `want` finished tiles in *ctr.  A time limit that expires (it never should:
-// the producer does not depend on this stream) is reported through the factorisation's status word instead of letting the consumers
-// read tiles that are not there.
-__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *info)
+// the producer does not depend on this stream) is reported through the factorisation's STALL word -- a word of its own, not the
+// potrf status: a scheduling stall is not a non-positive pivot, and the caller answers it by refitting on the plain schedule, never
+// with jitter (the consumers behind an expired wait read tiles that are not there: that factor is discarded).
+__global__ void wait_count_kernel(const int *ctr, int want, unsigned long long limit_ticks, int *stall)
 {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
         if (__builtin_amdgcn_s_memrealtime() - t0 > limit_ticks) {
-            __hip_atomic_fetch_max(info, 0x3fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(stall, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
         __builtin_amdgcn_s_sleep(8);
@@ -860,35 +697,52 @@ __global__ void wait_count_kernel(const int *ctr, int want, unsigned long long l
 // waits for a count another launch produces; blockers sleep until a later launch releases them).  Counter-collecting profilers
 // (rocprofv3 --pmc) run one kernel at a time: the waits would sit out their time limits.  Checked once per process with a 2 ms probe: a
 // waiting kernel on one stream, the kernel that releases it launched afterwards on another.
+namespace {
+std::mutex g_conc_mu;
+std::map<std::pair<hipStream_t, hipStream_t>, bool> g_conc_seen;
+thread_local bool g_force_plain = false;   // (per host thread) set while a stalled fit is repeated: no kernel waits for a kernel of another stream
+}
+// forget every verdict (streams were destroyed, or a wait expired although its pair had been probed as concurrent)
+void chol_concurrency_forget()
+{
+    std::lock_guard<std::mutex> lk(g_conc_mu);
+    g_conc_seen.clear();
+}
+void chol_force_plain_schedule(bool on) { g_force_plain = on; }
+
 static bool streams_run_concurrently(hipStream_t a, hipStream_t b)
 {
     // a: the stream whose kernel waits, b: the stream whose later launch releases it.  Probed once per pair of streams (they come from
-    // the library's stream cache, so the same pairs recur) on the caller's own streams, both idle here: extra streams would change
+    // the library's stream cache, so the same pairs recur) on the caller's own streams: extra streams would change
     // which streams share a hardware queue.  Two streams of one priority class may share a hardware queue when the process has
     // more streams than the runtime has queues for that class: the waiting kernel then sits in front of its own release.
+    // The fit probes its pairs while its streams are still idle (chol_probe_streams, before the Gram launch): a busy releasing stream
+    // would read as "not concurrent" for the rest of the process.
+    if (g_force_plain) return false;
     if (const char *e = getenv("GPX_CONCURRENT_STREAMS")) return atoi(e) != 0;
     if (!a || !b) return false;
-    static std::mutex mu;
-    static std::map<std::pair<hipStream_t, hipStream_t>, bool> seen;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = seen.find({a, b});
-    if (it != seen.end()) return it->second;
-    int *w = nullptr;
+    std::lock_guard<std::mutex> lk(g_conc_mu);
+    auto it = g_conc_seen.find({a, b});
+    if (it != g_conc_seen.end()) return it->second;
+    double *wd = nullptr;                       // a scratch word from the library's pool (no hipMalloc / hipFree inside a fit)
     bool good = false;
-    if (hipMalloc((void **)&w, 2 * sizeof(int)) == hipSuccess) {
-        if (hipMemset(w, 0, 2 * sizeof(int)) == hipSuccess) {
+    if (dalloc(&wd, 2) == 0) {
+        int *w = reinterpret_cast<int *>(wd);
+        if (hipMemsetAsync(w, 0, 2 * sizeof(int), a) == hipSuccess && hipStreamSynchronize(a) == hipSuccess) {
             hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, a, (const int *)w, 1, 200000ull, w + 1);   // <= 2 ms
+            const bool l1 = hipGetLastError() == hipSuccess;
             hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, b, w, 1);
+            const bool l2 = hipGetLastError() == hipSuccess;
             int h[2] = {0, 1};
-            if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess &&
+            if (hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess && l1 && l2 &&
                 hipMemcpy(h, w, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
                 good = (h[1] == 0);
         }
-        (void)hipFree(w);
+        dfree(wd);
     }
     (void)hipGetLastError();
     if (getenv("GPX_DEBUG")) fprintf(stderr, "[gpx] concurrent-streams probe (%p waits, %p releases): %d\n", (void *)a, (void *)b, (int)good);
-    seen[{a, b}] = good;
+    g_conc_seen[{a, b}] = good;
     return good;
 }
 
@@ -903,6 +757,25 @@ static long reserve_below_tiles()
 {
     static const long v = [] { const char *e = getenv("GPX_RESERVE_TILES"); return e ? atol(e) : 3000L; }();
     return v;
+}
+
+static int blocker_stream_prio()
+{
+    static const int v = [] { const char *e = getenv("GPX_BLK_PRIO"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+// Probes every pair of streams the look-ahead schedule lets wait for each other (cached per pair).  Called by the fit while the
+// streams are still idle -- before the Gram launch is queued on `s`.
+void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top)
+{
+    if (!s_pan) return;
+    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    if (!concurrent || reserve_cus() == 0) return;
+    hipStream_t s_blk = stream_acquire(blocker_stream_prio());   // the cache hands the same stream to chol_factor's own acquire
+    if (!s_blk) return;
+    (void)(streams_run_concurrently(s_blk, s) && streams_run_concurrently(s_blk, s_pan) && (!s_top || streams_run_concurrently(s_blk, s_top)));
+    stream_release(s_blk, blocker_stream_prio());
 }
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
@@ -939,7 +812,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
     int nres = concurrent ? reserve_cus() : 0;
     // (high priority: that class has its own hardware queues, which an application's ordinary streams do not crowd)
-    static const int blk_prio = [] { const char *e = getenv("GPX_BLK_PRIO"); return e ? atoi(e) : 1; }();
+    const int blk_prio = blocker_stream_prio();
     hipStream_t s_blk = nres ? stream_acquire(blk_prio) : nullptr;
     if (s_blk && !(streams_run_concurrently(s_blk, s) && streams_run_concurrently(s_blk, s_pan) && (!s_top || streams_run_concurrently(s_blk, s_top)))) {
         // the blockers would sit in front of launches their release depends on
@@ -947,10 +820,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         s_blk = nullptr;
         nres = 0;
     }
-    int *stop_flag = info_dev + 1, *placed = info_dev + 2;
+    int *stall = info_dev + 1, *stop_flag = info_dev + 2, *placed = info_dev + 3;   // info_dev: [0] potrf status, [1] stall, then these, then sig
     static const int trap_env = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
     const int trap_on = trap_env && concurrent;
-    int *sig = info_dev + 3;                                   // CHOL_NBP counters per panel: finished narrow tiles of its trapezoid launch by tile column
+    int *sig = info_dev + 4;                                   // CHOL_NBP counters per panel: finished narrow tiles of its trapezoid launch by tile column
     bool reserved = false, released = false;
     hipEvent_t ev_blk = nullptr;
     auto release_blockers = [&](hipStream_t on) {
@@ -1013,13 +886,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 break;
             }
             if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
+                // (the column solves keep their small tiles and share the reserved CUs with the chain: measured better than 224-register
+                // tiles that stay off them, fit 28.9 -> 28.1 ms)
                 GPX_TRY(reserve_now());
-                {   // GPX_TOP_BIG=3 keeps the column solves off the reserved CUs (224-register tiles).  That was the better choice
-                    // while the trapezoid launch (208 registers then) leaked onto those CUs; with the bulk kept off them the small
-                    // tiles, which share the reserved CUs with the chain, are: fit 28.9 -> 28.1 ms
-                    const char *e = getenv("GPX_TOP_BIG");
-                    for (int64_t q = p; q <= P; ++q) tops[q].big = e ? atoi(e) : 0;
-                }
             }
             const int64_t K = (B1 - B0) * TILE;
             // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
@@ -1060,7 +929,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                         // from a stream of its own was measured too: one more cross-stream edge per panel, fit +1.4 ms.
                         tops[p + 1].colsig = sig + p * CHOL_NBP;
                         tops[p + 1].colwant = (int)nrem;
-                        tops[p + 1].info = info_dev;
+                        tops[p + 1].stall = stall;
                     } else {
                         GPX_HIP(hipEventRecord(ev_tu[p], s));
                         GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));

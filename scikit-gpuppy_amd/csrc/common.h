@@ -160,10 +160,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
 int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
-                   hipStream_t s, Profiler *prof, int big_tiles = 0, int ktrim = 0, int tri = 0);
-// the same product on the small-footprint kernel that is placed at once next to a saturating bulk launch (gemm.hip)
-int launch_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t N,
-                          int64_t K, double alpha, double beta, hipStream_t s, Profiler *prof);
+                   hipStream_t s, Profiler *prof, int ktrim = 0, int tri = 0);
 // narrow update + bulk SYRK of a panel as ONE trapezoid launch that counts its finished narrow tiles in *sig_dev (gemm.hip)
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
                             double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof);
@@ -186,6 +183,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr,
                 const std::function<int()> *after_fork = nullptr,
                 const std::function<int(int64_t, int64_t, bool)> *panel_final = nullptr);
+// info_dev (device ints, zero before the call): [0] potrf status (1-based failing column), [1] STALL (an in-kernel wait of the
+// look-ahead schedule expired: the factor is invalid, refit with chol_force_plain_schedule(true)); with s_pan != nullptr the schedule
+// uses 4 + nblk + 8 ints of it.
+void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top);
+void chol_concurrency_forget();
+void chol_force_plain_schedule(bool on);
 // panel_final(p, slack, last): queued on the main stream s at a point where the columns of the outer panels 0..p are final for work
 // on s; slack = outer panels whose trailing update is still to come (small = the main stream is about to idle underneath the chain:
 // the place for work that rides along), last = the factorisation has nothing more to queue

@@ -403,25 +403,11 @@ int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64
     return 0;
 }
 
-// The 32/64-row tiles with the bulk kernel's register footprint (224 VGPRs): the same product, but the workgroup cannot settle on
-// the CUs reserved for the diagonal chain (chol.hip: 192 registers per SIMD are free there).  For the column solves that run
-// alongside the chain: they keep competing with the bulk for places, as before, instead of crowding the chain's CUs.
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_fat_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int K,
-                                                                double alpha, double beta)
-{
-    constexpr int BTM = 32 * WM, BTN = 32 * WN;
-    __shared__ __attribute__((aligned(1024))) double smem[2 * (BTM + BTN) * 16];
-    asm volatile("v_mov_b32 v223, 0" ::: "v223");
-    gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, (int)blockIdx.x, (int)blockIdx.y, 0, K, alpha, beta, smem);
-}
-
 // tiles128 below this -> use the 64x64-tile variant (4x the workgroups, same math)
 constexpr double SMALL_GRID_TILES = 192.0;
 
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
-                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int big_tiles, int ktrim,
-                   int tri)
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int ktrim, int tri)
 {
     if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
@@ -480,17 +466,11 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         const GemmBatch pa_ = {0, 0, 0, tri == GEMM_TRI_B_LOWER ? GEMM_TRI_B_LOWER_PAIRED : GEMM_TRI_B_UPPER_PAIRED};
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
                            (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
-    } else if (tiles >= SMALL_GRID_TILES || (big_tiles == 1 && !in_place) || big_tiles == 2) GPX_LAUNCH(4, 4);   // big_tiles: the caller runs several such launches concurrently (2: also in place -- one 128-wide column tile per row block)
-    else if (lower_only && tiles <= 40.0 && K >= 512 && !ktrim) GPX_LAUNCH(1, 1);   // a 1024 x 1024 square with a long contraction (the update that
+    } else if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
+    else if (lower_only && tiles <= 40.0 && K >= 512 && K <= 2048 && !ktrim) GPX_LAUNCH(1, 1);   // a 1024 x 1024 square with a long contraction (the update that
                                                                                      // gates the factorisation's next chain): 32 x 32 tiles put two
                                                                                      // workgroups on every CU, 64 x 64 tiles one on half of them
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
-    else if (N == TILE && big_tiles == 3) {   // the same 32/64-row tiles, kept off the CUs reserved for the chain (above)
-        if (tiles >= SMALL_GRID_TILES / 2)
-            hipLaunchKernelGGL((gemm_nt_f64_fat_kernel<2, 4>), dim3(1, (unsigned)(M / 64)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta);
-        else
-            hipLaunchKernelGGL((gemm_nt_f64_fat_kernel<1, 4>), dim3(1, (unsigned)(M / 32)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta);
-    }
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
         if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);
         else GPX_LAUNCH(1, 4);
@@ -500,150 +480,6 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     return 0;
 }
 
-
-// ------------------------------------------------------------------------------------------------
-// "Sliver" variant for the latency-bound products on the factorisation's critical path (the 128-column TRSM and rank-128
-// update steps of the diagonal chain, the pipelined column solves).  Measured on the box (tools/native/probe_slot.hip): next
-// to the saturating bulk launch -- two workgroups per CU, 64 KB of LDS and 224 VGPRs each -- a workgroup that needs at most
-// 16 KB of LDS and 64 VGPRs is placed within 3 us on any CU, anything larger waits for a bulk workgroup to retire: 40-130 us on
-// average per launch, because equal-length tiles retire in bursts.  So this kernel lives in what two bulk workgroups leave
-// free: 64 VGPRs (4 accumulator tiles per wave), a ring of k = 4 deep LDS stages filled by LDS-DMA (32-byte rows, 32 rows per
-// wave-instruction; the 16-byte granule is XOR-swizzled with bit 3 of the row so that a half-wave's fragment read covers 32
-// distinct 8-byte bank slots).  (1,4): 32 x 128 tile (one column tile per row block: in-place products are safe), three
-// stages of 5 KB; (2,2): 64 x 64 tile, four stages of 4 KB.
-// ------------------------------------------------------------------------------------------------
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 8) void gemm_nt_sliver_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
-                                                                int K, double alpha, double beta)
-{
-    constexpr int BTM = 32 * WM, BTN = 32 * WN, WTM = 16 * WM, WTN = 16 * WN;
-    constexpr int NA = BTM / 32, NB = BTN / 32;            // DMA instructions per stage for the A / B image (32 rows each)
-    constexpr int STAGE = (BTM + BTN) * 4;                 // doubles
-    constexpr int NS = (16384 / 8) / STAGE;                // ring depth: 3 for (1,4), 4 for (2,2)
-    static_assert(NS >= 3, "ring too shallow");
-    // every wave issues the same number of DMA instructions per stage (the s_waitcnt vmcnt bookkeeping below is a constant):
-    // (2,2): instruction `wave` of the four; (1,4): its quarter of B plus the one A instruction (fetched by all four waves:
-    // 1 KB, harmless)
-    static_assert((NA + NB == 4) || (NA == 1 && NB == 4), "tile shape not supported");
-    constexpr bool SHARED_A = (NA == 1 && NB == 4);
-    constexpr int PER = SHARED_A ? 2 : 1;                  // DMA instructions per wave and stage
-    __shared__ __attribute__((aligned(1024))) double smem[NS * STAGE];
-    const int t = threadIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int bx = blockIdx.x, by = blockIdx.y;
-
-    // DMA: lane -> (row = 32 j + lane>>1, LDS granule lane&1); the granule fetched is (lane&1) ^ bit 3 of the row
-    const int drow = lane >> 1;
-    const long sg = (long)((lane & 1) ^ ((drow >> 3) & 1));
-    const char *Abase = reinterpret_cast<const char *>(A + (long)by * BTM * lda);
-    const char *Bbase = reinterpret_cast<const char *>(B + (long)bx * BTN * ldb);
-    // this wave's instruction j (image rows 32 j ..): from A if j < NA, else from B
-    const int j0 = SHARED_A ? 1 + wave : wave;
-    const bool j0_is_a = j0 < NA;
-    const char *base0 = j0_is_a ? Abase : Bbase;
-    const unsigned off0 = (unsigned)(((long)(32 * (j0_is_a ? j0 : j0 - NA) + drow) * (j0_is_a ? lda : ldb) + 2 * sg) * 8);
-    const unsigned offa = (unsigned)(((long)drow * lda + 2 * sg) * 8);   // SHARED_A: the A instruction (rows 0..31)
-    const unsigned lds_base = (unsigned)(unsigned long)(__attribute__((address_space(3))) double *)smem;
-#define GPX_SL_DMA(SBASE, VOFF, LDSBYTES)                                                                           \
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(LDSBYTES), "v"(VOFF), "s"(SBASE) : "memory");
-    auto dma_stage = [&](int kt) {
-        const int buf = kt % NS;
-        const char *p0 = gpx_uniform_ptr(base0 + (long)kt * 32);
-        GPX_SL_DMA(p0, off0, __builtin_amdgcn_readfirstlane(lds_base + 8u * (unsigned)(buf * STAGE + j0 * 128)))
-        if (SHARED_A) {
-            const char *pa = gpx_uniform_ptr(Abase + (long)kt * 32);
-            GPX_SL_DMA(pa, offa, __builtin_amdgcn_readfirstlane(lds_base + 8u * (unsigned)(buf * STAGE)))
-        }
-    };
-    const int nk = K / 4;
-    for (int kt = 0; kt < NS - 1 && kt < nk; ++kt) dma_stage(kt);
-
-    double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
-    v4d acc[WM][WN];
-    if (beta != 0.0) {
-        const double bs = beta / alpha;
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                v4d c0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) c0[r] = bs * Cw[(long)(i * 16 + 4 * r) * ldc + j * 16];
-                acc[i][j] = c0;
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // fragment of row r (local), k = fq: granule (fq>>1) ^ bit 3 of r, half fq&1.  Rows of a wave tile start at multiples of 16.
-    typedef const volatile __attribute__((address_space(3))) double lds_vdouble;
-    lds_vdouble *vsm = (lds_vdouble *)smem;
-    const int foff = fr * 4 + ((((fq >> 1) ^ ((fr >> 3) & 1)) << 1) | (fq & 1));
-    const int a_row = wr * WTM * 4 + foff, b_row = BTM * 4 + wc * WTN * 4 + foff;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nxt = kt + NS - 1;
-        if (nxt < nk) dma_stage(nxt);                      // into the buffer whose readers all passed the last barrier
-        const int off = (kt % NS) * STAGE;
-        double fa[WM], fb[WN];
-#pragma unroll
-        for (int i = 0; i < WM; ++i) fa[i] = vsm[off + a_row + i * 64];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) fb[j] = vsm[off + b_row + j * 64];
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        if (kt + 1 < nk) {
-            // stage kt + 1 must have landed: all but this wave's newest NS - 2 stages (fewer near the end)
-            if (nxt < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-    }
-#undef GPX_SL_DMA
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + 4 * r) * ldc + j * 16] = alpha * acc[i][j][r];
-}
-
-static int sliver_enabled()
-{
-    static const int v = [] { const char *e = getenv("GPX_SLIVER"); return e ? atoi(e) : 1; }();
-    return v;
-}
-
-// C = alpha A B^T + beta C on the sliver kernel.  N == 128: 32 x 128 tiles (in-place products allowed: C == A or C == B);
-// otherwise 64 x 64 tiles (M, N multiples of 64).  K a multiple of 4.
-int launch_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t N,
-                          int64_t K, double alpha, double beta, hipStream_t s, Profiler *prof)
-{
-    if (!sliver_enabled()) return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, 0, s, prof);
-    if (M % 64 || N % 64 || K % 4 || K <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0 ||
-        (((C == A) || (C == B)) && N != TILE)) {
-        gpx_set_error("launch_gemm_nt_sliver: shape/alignment not supported (M=%ld N=%ld K=%ld)", (long)M, (long)N, (long)K);
-        return GPX_ERR_BAD_ARG;
-    }
-    if (M == 0 || N == 0) return 0;
-    ProfScope ps(prof, s, GPX_K_GEMM_SMALL, 2.0 * (double)M * (double)N * (double)K, 2);
-    if (N == TILE)
-        hipLaunchKernelGGL((gemm_nt_sliver_kernel<1, 4>), dim3(1, (unsigned)(M / 32)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc,
-                           (int)K, alpha, beta);
-    else
-        hipLaunchKernelGGL((gemm_nt_sliver_kernel<2, 2>), dim3((unsigned)(N / 64), (unsigned)(M / 64)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C,
-                           (long)ldc, (int)K, alpha, beta);
-    GPX_HIP(hipGetLastError());
-    return 0;
-}
 
 // batch of independent products C_z = alpha A_z B_z^T + beta C_z, z = (p, q): operand z sits at base + p * sp + q * sq
 // (GemmBatch per operand; nq = number of q per p).  Small problems (the recursive doubling of the diagonal-square
@@ -835,12 +671,6 @@ extern "C" int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, in
                                int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only, void *stream)
 {
     return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, lower_only, (hipStream_t)stream, nullptr);
-}
-
-extern "C" int gpx_dev_gemm_nt_sliver(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
-                                      int64_t M, int64_t N, int64_t K, double alpha, double beta, void *stream)
-{
-    return launch_gemm_nt_sliver(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, (hipStream_t)stream, nullptr);
 }
 
 extern "C" int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols,

@@ -233,7 +233,7 @@ static int spgp_solve_into_z(gpx_spgp *h, const double *L, const double *Dinv, d
 {
     double *linv = linv_keep ? linv_keep : h->scrB;
     GPX_TRY(spgp_linv(h, L, Dinv, linv, linv_t_keep));   // linv_t_keep: where the caller wants inv(L)^T left (default: scratch)
-    return launch_gemm_nt(h->Knm, h->mpad, linv, h->mpad, h->Z, h->mpad, h->npad, h->mpad, h->mpad, 1.0, 0.0, 0, h->stream, nullptr, 0, 0,
+    return launch_gemm_nt(h->Knm, h->mpad, linv, h->mpad, h->Z, h->mpad, h->npad, h->mpad, h->mpad, 1.0, 0.0, 0, h->stream, nullptr, 0,
                           GEMM_TRI_B_LOWER);
 }
 
@@ -366,8 +366,8 @@ extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, doubl
             GPX_TRY(launch_gram(xqw, qc, h->xbw, h->m, d, h->v, 0.0, 0, 1, Ka, mp, qp, mp, s, nullptr));   // K_*M
             GPX_TRY(launch_predict_reduce(Ka, mp, qc, mp, h->beta, 0.0, mean, unused, s, nullptr));       // K_*M beta
             // K_*M L^-T for both factors: one product each with the explicit inverse (zero triangle skipped)
-            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvM, mp, Kb, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_LOWER));
-            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvB, mp, Kc, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_LOWER));
+            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvM, mp, Kb, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, GEMM_TRI_B_LOWER));
+            GPX_TRY(launch_gemm_nt(Ka, mp, h->LinvB, mp, Kc, mp, qp, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, GEMM_TRI_B_LOWER));
             GPX_TRY(launch_predict_reduce(Kb, mp, qc, mp, h->mzero, h->v + h->vt, unused, va, s, nullptr));   // v + vt - |K_*M L_M^-T|^2
             GPX_TRY(launch_predict_reduce(Kc, mp, qc, mp, h->mzero, 0.0, unused, vb, s, nullptr));            //        - |K_*M L_B^-T|^2
             GPX_TRY(vec_op(VEC_SUB, qc, qc, 0.0, va, vb, var, nullptr, s));
@@ -632,7 +632,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         GPX_TRY(spgp_wtw(h, W2, Qb, 1.0, -1.0));
         GPX_TRY(launch_symmetrize_lower(Qb, mp, mp, s));
         hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
-        GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, 0, GEMM_TRI_B_UPPER));   // Z = Kbar^T = Vbar^T L^-1 (L^-T upper: half the contraction)
+        GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, GEMM_TRI_B_UPPER));   // Z = Kbar^T = Vbar^T L^-1 (L^-T upper: half the contraction)
         GPX_TRY(launch_gemm_nt(LinvT, mp, Qb, mp, Y, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));     // Y = L^-T Qb   (Qb symmetric)
         GPX_TRY(launch_gemm_nt(Y, mp, LinvT, mp, Qbar, mp, mp, mp, mp, 1.0, 0.0, 0, s, nullptr));   // Qbar = L^-T Qb L^-1
         GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 0.0, 0, 1, Qk, mp, mp, mp, s, nullptr)); // K_M (no jitter), zero padded

@@ -415,7 +415,7 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
     if (!ts || !ts->Pl) { gpx_set_error("trsm_right_lt_squares: solver not prepared"); return GPX_ERR_STATE; }
     if (np == 1) {
         const int64_t k0 = p0 * PB, K = std::min<int64_t>(PB, ts->npad - k0);
-        return launch_gemm_nt(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, K, 1.0, 0.0, 0, s, prof, 0, 0, GEMM_TRI_B_LOWER);
+        return launch_gemm_nt(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, K, 1.0, 0.0, 0, s, prof, 0, GEMM_TRI_B_LOWER);
     }
     int64_t h = 1;
     while (h * 2 < np) h *= 2;

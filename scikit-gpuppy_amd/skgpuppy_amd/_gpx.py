@@ -78,7 +78,6 @@ SIGNATURES = {
     "gpx_dev_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
     "gpx_dev_gram_scaled": (_int, [_dp, _i64, _dp, _i64, _int, _dbl, _dbl, _int, _int, _dp, _i64, _i64, _i64, ctypes.c_void_p]),
     "gpx_dev_gemm_nt": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, _int, ctypes.c_void_p]),
-    "gpx_dev_gemm_nt_sliver": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, ctypes.c_void_p]),
     "gpx_dev_syrk_trap": (_int, [_dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dbl, _dbl, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_dev_potrf_leaf": (_int, [_dp, _i64, _dp, _dp, ctypes.c_void_p, _int, ctypes.c_void_p]),
     "gpx_dev_chol_panel": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),

@@ -140,31 +140,43 @@ class TorchComm(object):
         if self._split_ok and self.nccl and (self.world > 1 or exercise_single_rank):
             self._split_ok = self._probe_split()
 
+    def _agree(self, ok):
+        """minimum of `ok` over the ranks (a plain all-reduce: the one collective every backend has)"""
+        import torch
+        t = torch.tensor([int(ok)], dtype=torch.int32, device="cuda")
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
     def _probe_split(self):
-        """one tiny scatter + in-place all-gather on device tensors; the verdict is the minimum over the ranks"""
+        """one tiny scatter + in-place all-gather on device tensors.  The ranks agree on the verdict after EACH of the two
+        collectives: a rank on which the scatter raised must not leave its peers inside the all-gather (they would wait in a
+        different collective than the all-reduce this rank goes on to -- a hang, not an error)."""
         import torch
         dist = self.dist
-        ok = 1
-        try:
-            buf = torch.zeros(self.world * 2, dtype=torch.float64, device="cuda")
-            if self.rank == 0:
-                buf += torch.arange(self.world * 2, dtype=torch.float64, device="cuda") + 1.0
-            parts = list(buf.view(self.world, 2).unbind(0))
-            dist.scatter(parts[self.rank], scatter_list=parts if self.rank == 0 else None, src=0, group=self.group)
-            dist.all_gather_into_tensor(buf, parts[self.rank], group=self.group)
-            torch.cuda.synchronize()
-            if not torch.equal(buf.cpu(), torch.arange(self.world * 2, dtype=torch.float64) + 1.0):
-                ok = 0
-        except (RuntimeError, ValueError, TypeError) as exc:
-            sys.stderr.write("[skgpuppy_amd.distributed] scatter + all-gather unavailable on rank %d (%s)\n" % (self.rank, exc))
-            ok = 0
-        t = torch.tensor([ok], dtype=torch.int32, device="cuda")
-        if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-        agreed = bool(int(t.item()))
-        if not agreed and self.rank == 0:
+        buf = torch.zeros(self.world * 2, dtype=torch.float64, device="cuda")
+        if self.rank == 0:
+            buf += torch.arange(self.world * 2, dtype=torch.float64, device="cuda") + 1.0
+        parts = list(buf.view(self.world, 2).unbind(0))
+
+        def attempt(what, fn):
+            try:
+                fn()
+                torch.cuda.synchronize()
+                return 1
+            except (RuntimeError, ValueError, TypeError) as exc:
+                sys.stderr.write("[skgpuppy_amd.distributed] %s unavailable on rank %d (%s)\n" % (what, self.rank, exc))
+                return 0
+
+        ok = self._agree(attempt("scatter", lambda: dist.scatter(parts[self.rank], scatter_list=parts if self.rank == 0 else None,
+                                                                  src=0, group=self.group)))
+        if ok:
+            ok = self._agree(attempt("in-place all-gather", lambda: dist.all_gather_into_tensor(buf, parts[self.rank], group=self.group)))
+        if ok:
+            ok = self._agree(torch.equal(buf.cpu(), torch.arange(self.world * 2, dtype=torch.float64) + 1.0))
+        if not ok and self.rank == 0:
             sys.stderr.write("[skgpuppy_amd.distributed] panel transport: plain broadcast\n")
-        return agreed
+        return ok
 
     def broadcast(self, buf, src, ops=None):
         dist = self.dist
@@ -272,6 +284,16 @@ class GpxOps(object):
         self._operand = {}                              # panel -> (device pointer, leading dimension, first row) of its update operand
         self._ev_avail = {}                             # panel -> event: message complete (recorded on main)
         self._ev_main_done = {}                         # panel -> event: main's updates with that panel are queued
+        # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's panel step (side stream) and around the main stream's wait for
+        # each panel's message -- what the first multi-GPU run is judged on (projected timeline)
+        self._timed = os.environ.get("GPX_SHARD_TIMING", "0") not in ("", "0")
+        self._pairs = {"chol_panel_ms": [], "exposed_wait_ms": []}
+        self.timing = {}
+
+    def _mark(self, stream):
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
 
     # ---- helpers ------------------------------------------------------------------------------
     def _stream_ptr(self, st):
@@ -338,6 +360,8 @@ class GpxOps(object):
         with torch.cuda.stream(self.side):
             if prev is not None:
                 self.side.wait_event(self._ev_avail[prev])        # panel `prev` has arrived
+            t0 = self._mark(self.side) if self._timed else None
+            if prev is not None:
                 # update with `prev` + factorisation in one native call: square first (the chain starts at once), the rows
                 # below on the library's side stream ahead of their column solves
                 ptr, ldp, first = self._operand[prev]
@@ -350,6 +374,8 @@ class GpxOps(object):
                 st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
                                                  self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
             self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
+            if self._timed:
+                self._pairs["chol_panel_ms"].append((t0, self._mark(self.side)))
             buf = self._slot(p)
             if self.layout.world > 1:
                 # pack: the slot's previous panel (p - 2) must have been read by the main stream's updates
@@ -374,9 +400,12 @@ class GpxOps(object):
         torch = self.torch
         b0, b1, c0, w, rows = self._geom(p)
         with torch.cuda.stream(self.main):
+            t0 = self._mark(self.main) if self._timed else None
             work.wait()                                           # main stream waits for the message (no host block on RCCL)
             if self.layout.owner(p) == self.rank:
                 self.main.wait_stream(self.side)                  # factorisation (and pack) of the own panel
+            if self._timed:                                       # main-stream idle time in front of panel p's updates
+                self._pairs["exposed_wait_ms"].append((t0, self._mark(self.main)))
             ev = torch.cuda.Event()
             ev.record(self.main)
         self._ev_avail[p] = ev
@@ -410,6 +439,9 @@ class GpxOps(object):
     def finish(self):
         self.side.synchronize()
         self.main.synchronize()
+        if self._timed:
+            self.timing = {k: float(sum(a.elapsed_time(b) for a, b in v)) for k, v in self._pairs.items()}
+            self.timing["panels_owned"] = len(self._pairs["chol_panel_ms"])
         return int(self.info.item())
 
 
@@ -499,6 +531,7 @@ class ShardedGaussianProcess(object):
                 raise np.linalg.LinAlgError("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter" % info)
             self._ops = ops
             self.jitter = jitter
+            self.fit_timing = dict(ops.timing)        # GPX_SHARD_TIMING=1: owner-side panel step / exposed message waits of this fit (ms)
             st = _gpx.lib.gpx_adopt_factor(ctypes.c_void_p(self._x_dev.data_ptr()), ctypes.c_void_p(self._t_dev.data_ptr()),
                                            self.n, self.d, _gpx.ptr(self.theta_min), ops._p(ops.L), ops._p(ops.Dinv),
                                            ops._p(ops.diag), jitter, None, ctypes.byref(self._h))
@@ -659,10 +692,17 @@ def bench_main(args):
     os.dup2(2, 1)
     # a stuck collective must not hold the node: after GPX_BENCH_WATCHDOG seconds (default 1200, 0 = never) every rank writes its
     # Python stacks to stderr and exits non-zero
+    # (a STALL detector, re-armed after every step and every leg: a long but progressing run -- many steps, the C4 one-GPU
+    # reference leg -- is never cut off)
     watchdog = int(os.environ.get("GPX_BENCH_WATCHDOG", "1200"))
-    if watchdog > 0:
-        import faulthandler
-        faulthandler.dump_traceback_later(watchdog, exit=True)
+    import faulthandler
+
+    def rearm():
+        if watchdog > 0:
+            faulthandler.cancel_dump_traceback_later()
+            faulthandler.dump_traceback_later(watchdog, exit=True)
+    rearm()
+    os.environ.setdefault("GPX_SHARD_TIMING", "1")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -696,7 +736,11 @@ def bench_main(args):
         if timed:
             t_fit += b - a
             t_pred += c - b
+            for k_, v_ in getattr(gp, "fit_timing", {}).items():
+                shard_ms[k_] = shard_ms.get(k_, 0.0) + v_
+        rearm()
 
+    shard_ms = {}
     for _ in range(args.warmup):
         step(False)
     dist.barrier()
@@ -733,6 +777,7 @@ def bench_main(args):
             torch.cuda.synchronize()
             c = time.perf_counter()
             _gpx.lib.gpx_free(h1)
+            rearm()
             if rep >= args.warmup:
                 acc[0] += b - a
                 acc[1] += c - b
@@ -742,7 +787,14 @@ def bench_main(args):
                    "value": (N + M) * k_ / (acc[0] + acc[1]), "steps": args.steps, "warmup": args.warmup,
                    "note": "same workload, one GPU, single-GPU library path (= bench.py --gpus 1 --workload %s), timed on rank 0 "
                            "after the sharded legs with the same warm-up / step counts" % (args.workload or "c4")}
+    rearm()
     dist.barrier()
+    # per-rank owner-side panel time and exposed message waits of the timed fits (ms per step), gathered on rank 0
+    keys = ["chol_panel_ms", "exposed_wait_ms", "panels_owned"]
+    mine_t = torch.tensor([shard_ms.get(k_, 0.0) / max(1, args.steps) for k_ in keys], dtype=torch.float64, device=dev)
+    all_t = [torch.zeros_like(mine_t) for _ in range(world)]
+    dist.all_gather(all_t, mine_t)
+    per_rank = [{k_: float(v_) for k_, v_ in zip(keys, row.cpu())} for row in all_t]
     if rank == 0:
         flops = N ** 3 / 3.0 + float(N) * N * M
         line = (json.dumps({
@@ -764,6 +816,9 @@ def bench_main(args):
             "fit_ms": tf / args.steps * 1e3,
             "predict_ms": tp / args.steps * 1e3,
             "one_gpu_same_workload": one_gpu,
+            # strong scaling against the SAME workload on one GPU (same warm-up / steps, timed after the sharded legs on rank 0)
+            "scaling_efficiency": (one_gpu["ms_per_step"] / (world * el / args.steps * 1e3)) if one_gpu else None,
+            "per_rank_fit": per_rank,
             "roofline": {"kernel": "gemm_nt_f64_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
                          "achieved": flops * args.steps / el / 1e12 / world, "peak": bench_mod.FP64_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops * args.steps / el / 1e12 / world / bench_mod.FP64_MFMA_PEAK_TFLOPS,

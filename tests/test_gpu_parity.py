@@ -1291,9 +1291,11 @@ for rep in range(3):
     gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
     best = min(best, time.perf_counter() - a)
     beta = gp._get_beta()
+    jit = gp._dev().jitter()
     gp._dev().close()
 np.save(sys.argv[1], beta)
 print("FIT_SECONDS %%.4f" %% best)
+print("JITTER %%g" %% jit)
 """
 
 
@@ -1324,3 +1326,28 @@ def test_fallback_schedules_agree_and_do_not_stall(tmp_path):
         # (the schedules differ in how the trailing update is cut into launches, not in any tile's arithmetic: alpha agrees to rounding)
         np.testing.assert_allclose(betas[name], betas["default"], rtol=0, atol=1e-9 * np.abs(betas["default"]).max())
         assert secs[name] < 5 * secs["default"] + 0.02, (name, secs)
+
+
+@pytest.mark.gpu
+def test_stalled_handoff_is_answered_by_a_plain_refit_not_by_jitter(tmp_path):
+    """An in-kernel wait of the look-ahead schedule that expires (GPX_TEST_FORCE_STALL: the first wait of the process asks for a count
+    that never comes and gives up after 10 us) sets the factorisation's STALL word, not the potrf status: the fit must discard that
+    factor and repeat it on the plain schedule -- same alpha as an undisturbed fit, NO jitter (round 3 mapped the timeout onto the
+    'not positive definite' code and silently refitted K + 1e-5 I)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _SCHEDULE_WORKER % {"root": ROOT, "pkg": os.path.join(ROOT, "scikit-gpuppy_amd")}
+    betas = {}
+    for name, extra in {"default": {}, "forced_stall": {"GPX_TEST_FORCE_STALL": "1", "GPX_DEBUG": "1"}}.items():
+        env = dict(os.environ)
+        env.update(extra)
+        out = tmp_path / (name + ".npy")
+        r = subprocess.run([sys.executable, "-c", code, str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        assert [l for l in r.stdout.splitlines() if l.startswith("JITTER")][-1].split()[1] == "0", r.stdout
+        if name == "forced_stall":
+            assert "hand-off stalled: refit on the plain schedule" in r.stderr, r.stderr[-2000:]
+        betas[name] = np.load(out)
+    np.testing.assert_allclose(betas["forced_stall"], betas["default"], rtol=0, atol=1e-9 * np.abs(betas["default"]).max())

@@ -51,8 +51,8 @@ def test_register_budget_of_the_cu_reservation(tmp_path):
         assert alloc(u) == 512 - FREE, u                      # what the blockers hold
     for u in pick(chol, "potrf_trtri128_elim_kernel").values():
         assert alloc(u) <= FREE, u                            # the leaf must fit beside a blocker
-    # kernels that must stay OFF the reserved CUs: the 128 x 128-tile bulk kernels and the "fat" small-tile variant
-    for frag in ("gemm_nt_f64_trap_signal_kernel", "gemm_nt_f64_kernelILi4ELi4E", "gemm_nt_f64_fat_kernel"):
+    # kernels that must stay OFF the reserved CUs: the 128 x 128-tile bulk kernels
+    for frag in ("gemm_nt_f64_trap_signal_kernel", "gemm_nt_f64_kernelILi4ELi4E"):
         for k, u in pick(gemm, frag).items():
             assert alloc(u) > FREE, (k, u)
     # the chain's own small GEMMs must fit on them (two waves per SIMD)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Leaf kernel (potrf128 + trtri128 in one launch): correctness against numpy, stand-alone latency, and latency next to a
 saturating bulk SYRK on another stream (the situation inside the look-ahead factorisation).
-GPX_LEAF=old selects the previous (bpermute) formulation for comparison."""
+(Round 2's bpermute formulation, once selectable with GPX_LEAF=old, was removed in round 4.)"""
 import ctypes
 import os
 import sys
