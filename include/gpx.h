@@ -77,6 +77,20 @@ int gpx_logdet(gpx_handle *h, double *logdet);               /* log det K  (Cova
  * K [n,n] symmetric positive definite -> Kinv_out [n,n] (Cholesky on the GPU; status > 0 = not PD); logdet_out may be NULL. */
 int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, double *logdet_out);
 
+/* ---- a4/a5/a6 for ANY Covariance subclass: the operator interface with a SUPPLIED matrix ----
+ * The reference's GaussianProcess talks to the operator only through cov.inv_cov_matrix / cov.cov_matrix / cov.cov_matrix_ij
+ * (skgpuppy/GaussianProcess.py:39-41, :68-80), and the base-class inv_cov_matrix inverts whatever cov_matrix returns
+ * (skgpuppy/Covariance.py:167-187, +1e-5 I retry :180-185).  gpx_fit_matrix is that route on the device: K [n,n] (symmetric, the
+ * operator's own cov_matrix(x, theta); host or device pointer) is Cholesky-factored with the same look-ahead schedule and the same
+ * single +1e-5 I retry, alpha = K^-1 t_centered is solved.  The handle answers gpx_predict_kv, gpx_alpha, gpx_solve, gpx_chol_mul,
+ * gpx_kinv, gpx_chol*, gpx_logdet, gpx_nll, gpx_nll_grad_matrix, gpx_jitter_used; entry points that evaluate the GaussianCovariance
+ * kernel itself (gpx_predict, gpx_cjh, gpx_propagate_*, gpx_exact_mean, gpx_nll_grad) return GPX_ERR_STATE on it. */
+int gpx_fit_matrix(const double *K, const double *t_centered, int64_t n, void *stream, gpx_handle **out);
+/* estimate_many / estimate from the operator's own cross-covariance (GaussianProcess.py:68-80, :94-111): kv [m,n] =
+ * cov.cov_matrix_ij(x_star, x), kdiag [m] = diag(cov.cov_matrix(x_star)) (for estimate: cov(x_star, x_star));
+ * mean_out[m] = kv alpha (the caller adds `meant`), var_out[m] = kdiag - kv K^-1 kv^T.  Any handle. */
+int gpx_predict_kv(gpx_handle *h, const double *kv, int64_t m, const double *kdiag, double *mean_out, double *var_out);
+
 /* ---- a6/a7: GaussianProcess.estimate_many / estimate  (skgpuppy/GaussianProcess.py:68-111) ----
  * mean_out[m] = kv alpha   (the caller adds `meant`),  var_out[m] = v + vt - kv K^-1 kv^T.
  * Never forms the M x M matrices of the reference. */
@@ -141,6 +155,14 @@ int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *
  * nll = N/2 log 2pi + 1/2 log det K + 1/2 t^T K^-1 t ;  grad_out[2+d] = d nll / d theta. */
 int gpx_nll(gpx_handle *h, double *nll);
 int gpx_nll_grad(gpx_handle *h, double *grad_out);
+
+/* One entry of Covariance._d_nll_d_theta for ANY operator (skgpuppy/Covariance.py:266-282): dK [n,n] = the operator's own
+ * _d_cov_matrix_d_theta(x, theta, j); *grad_out = 1/2 tr(K^-1 dK) - 1/2 alpha^T dK alpha in one pass over K^-1 and dK.  Any handle. */
+int gpx_nll_grad_matrix(gpx_handle *h, const double *dK, double *grad_out);
+/* out[r] = M V[r] for a supplied symmetric matrix M [n,n] and nrhs <= 64 vectors V [nrhs,n] (rows): the device route for the
+ * explicit `Kinv` argument of UncertaintyPropagationApprox._get_sigma2 / _get_variance_rest
+ * (skgpuppy/UncertaintyPropagation.py:412-481) when it is not the fitted model's own. */
+int gpx_symv(const double *M, int64_t n, const double *V, int nrhs, double *out);
 
 /* ---- "next" row f3: Snelson sparse pseudo-input GP (SPGPCovariance, skgpuppy/Covariance.py:692-1019) ----
  * theta = [log v, log vt, log w_1..d] (the GaussianCovariance part of the reference's theta), xb = the m x d

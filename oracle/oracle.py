@@ -231,6 +231,141 @@ class OracleGP(object):
 
 
 # --------------------------------------------------------------------------------------------
+# L2b: the GENERIC operator interface  (reference: the base class skgpuppy/Covariance.py:111-337 and GaussianProcess talking to
+# it only through that interface, skgpuppy/GaussianProcess.py:19-111).  Restated so that operators that are NOT the built-in
+# kernel -- a from-scratch subclass implementing __call__, a GaussianCovariance subclass with its own cov_matrix_ij -- have a
+# checker; pinned by tests/golden/generic_ops.npz (tools/gen_golden.py --generic runs the same operators on the genuine reference).
+# --------------------------------------------------------------------------------------------
+class OracleCovariance(object):
+    """Covariance (Covariance.py:111-337): everything from the subclass's scalar __call__."""
+
+    def __call__(self, xi, xj, theta):
+        raise NotImplementedError
+
+    def cov_matrix_ij(self, xi, xj, theta):
+        # Covariance.py:137-152
+        K = np.zeros((len(xi), len(xj)))
+        for i in range(len(xi)):
+            for j in range(len(xj)):
+                K[i, j] = self(xi[i], xj[j], theta)
+        return K
+
+    def cov_matrix(self, x, theta):
+        # Covariance.py:155-164
+        return self.cov_matrix_ij(x, x, theta)
+
+    def inv_cov_matrix(self, x, theta, cov_matrix=None):
+        # Covariance.py:167-187
+        if cov_matrix is not None:
+            return inv(cov_matrix)
+        K = np.array(self.cov_matrix(x, theta))
+        try:
+            return inv(K)
+        except ValueError:
+            m = len(K)
+            L = cholesky(K + np.eye(m) * 1e-5, lower=True)
+            Linv = solve_triangular(L, np.eye(m), lower=True)
+            return np.dot(Linv.T, Linv)
+
+    def _log_det_cov_matrix(self, x, theta):
+        # Covariance.py:189-195
+        return np.linalg.slogdet(self.cov_matrix(x, theta))[1]
+
+    def _negativeloglikelihood(self, x, t, theta):
+        # Covariance.py:197-216
+        invK = self.inv_cov_matrix(x, theta)
+        return len(x) / 2.0 * np.log(2 * np.pi) + 0.5 * self._log_det_cov_matrix(x, theta) + 0.5 * np.dot(t.T, np.dot(invK, t))
+
+    def _d_cov_d_theta(self, xi, xj, theta, j):
+        # Covariance.py:219-233
+        eps = 1e-5
+        d = np.zeros(len(theta))
+        d[j] = eps
+        return (self(xi, xj, theta + d) - self(xi, xj, theta - d)) / (2 * eps)
+
+    def _d_cov_matrix_d_theta(self, x, theta, j):
+        # Covariance.py:236-265
+        K = np.zeros((len(x), len(x)))
+        for i1 in range(len(x)):
+            for i2 in range(len(x)):
+                K[i1, i2] = self._d_cov_d_theta(x[i1], x[i2], theta, j)
+        return K
+
+    def _d_nll_d_theta(self, x, t, theta):
+        # Covariance.py:266-282
+        Kinv = self.inv_cov_matrix(x, theta)
+        g = []
+        for j in range(len(theta)):
+            dK = self._d_cov_matrix_d_theta(x, theta, j)
+            g.append(0.5 * np.dot(np.ravel(Kinv.T), np.ravel(dK)) - 0.5 * np.dot(t.T, np.dot(Kinv, np.dot(dK, np.dot(Kinv, t)))))
+        return np.array(g)
+
+
+class OracleGaussianCovariance(OracleCovariance):
+    """GaussianCovariance (Covariance.py:435-689) as an operator object: vectorised cov_matrix_ij, cov_matrix = cov_matrix_ij + vt I,
+    closed-form derivative Grams that recompute the built-in Gram inline (:605-657: NOT through self.cov_matrix_ij)."""
+
+    def __call__(self, xi, xj, theta):
+        return scalar_cov(xi, xj, theta)
+
+    def cov_matrix_ij(self, xi, xj, theta):
+        return gram_ij(xi, xj, theta)
+
+    def cov_matrix(self, x, theta):
+        _v, vt, _w = unpack_theta(theta)
+        return self.cov_matrix_ij(x, x, theta) + vt * np.eye(len(x))
+
+    def _d_cov_matrix_d_theta(self, x, theta, j):
+        return d_gram_d_theta(x, theta, j)
+
+    def get_Jacobian(self, u, xi, theta):
+        return jacobian(u, xi, theta)
+
+    def get_Hessian(self, u, xi, theta):
+        return hessian(u, xi, theta)
+
+
+class OracleOperatorGP(object):
+    """GaussianProcess on ANY operator (GaussianProcess.py:19-111): Kinv = cov.inv_cov_matrix, predictions from cov.cov_matrix /
+    cov.cov_matrix_ij / cov.__call__ only.  Carries the attributes approx_parts / approx_dvh read (beta(), Kinv, theta_min, n, d)."""
+
+    def __init__(self, x, t, cov, theta):
+        self.x = x
+        self.n, self.d = np.shape(x)
+        self.meant = np.mean(t)
+        self.t = np.asarray(t, dtype=float) - self.meant
+        self.cov = cov
+        self.theta_min = np.asarray(theta, dtype=float)
+        self.Kinv = cov.inv_cov_matrix(self.x, self.theta_min)
+
+    def beta(self):
+        return np.dot(self.Kinv, self.t)
+
+    def estimate_many(self, x_stars):
+        xs = np.array(x_stars)
+        k = self.cov.cov_matrix(xs, self.theta_min)
+        kv = self.cov.cov_matrix_ij(xs, self.x, self.theta_min)
+        mean = np.dot(kv, np.dot(self.Kinv, self.t))
+        var = k - np.dot(kv, np.dot(self.Kinv, kv.T))
+        return mean + self.meant, np.diag(var)
+
+    def estimate(self, x_star):
+        xs = np.array(x_star)
+        k = self.cov(xs, xs, self.theta_min)
+        kv = self.cov.cov_matrix_ij(np.atleast_2d(xs), self.x, self.theta_min)
+        mean = np.dot(kv, np.dot(self.Kinv, self.t))
+        var = k - np.dot(kv, np.dot(self.Kinv, kv.T))
+        return mean[0] + self.meant, var[0, 0]
+
+    def cjh(self, u):
+        """UncertaintyPropagation.py:504-510 through the operator's own scalar kernel / Jacobian / Hessian"""
+        x = np.asarray(self.x)
+        return (np.array([self.cov(u, x[i], self.theta_min) for i in range(self.n)]),
+                np.array([self.cov.get_Jacobian(u, x[i], self.theta_min) for i in range(self.n)]),
+                np.array([self.cov.get_Hessian(u, x[i], self.theta_min) for i in range(self.n)]))
+
+
+# --------------------------------------------------------------------------------------------
 # L3: uncertainty propagation  (reference: skgpuppy/UncertaintyPropagation.py, ...2.pyx)
 # --------------------------------------------------------------------------------------------
 

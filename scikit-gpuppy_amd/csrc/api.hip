@@ -396,7 +396,7 @@ extern "C" void gpx_free(gpx_handle *h)
     h->prof.destroy();
     h->tri.release();
     if (h->external_factor) { h->L = nullptr; h->Dinv = nullptr; h->diagL = nullptr; }
-    double *bufs[] = {h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
+    double *bufs[] = {h->Ksrc, h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
@@ -405,6 +405,8 @@ extern "C" void gpx_free(gpx_handle *h)
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, main_stream_prio()); }
     delete h;
 }
+
+__global__ void pad_copy_kernel(const double *K, long n, double *L, long npad, double add_diag);
 
 // policy of the work that rides along with the factorisation (env GPX_FIT_RIDE=0: everything after it, as before round 3)
 static int fit_ride_enabled()
@@ -455,7 +457,12 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
         }
         return 0;
     };
-    if (h->npad <= c1 || !h->s_pan) {
+    if (h->Ksrc) {
+        // the operator supplied its matrix (gpx_fit_matrix): K (+ jitter on a retry) into the padded factor buffer, then the same schedule
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)h->npad), dim3(256), 0, s, (const double *)h->Ksrc, (long)h->n, h->L, (long)h->npad, add_diag);
+        GPX_HIP(hipGetLastError());
+        GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, nullptr, &ride));
+    } else if (h->npad <= c1 || !h->s_pan) {
         GPX_TRY(launch_gram(h->xs_w, h->n, h->xs_w, h->n, h->d, h->v, add_diag, 1, 2, h->L, h->npad, h->npad, h->npad, s, &h->prof));
         GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, nullptr, &ride));
     } else {
@@ -486,15 +493,20 @@ static void setup_lookahead_streams(gpx_handle *h)
     h->s_top = stream_acquire(side_stream_prio());
 }
 
+// Kmat != nullptr: the handle of a SUPPLIED covariance matrix (gpx_fit_matrix; n x n, host or device): no inputs, no kernel
+// parameters (d = 0) -- the factor, alpha, K^-1 and the solves work as for any handle, everything that evaluates the kernel does not.
 static int make_handle(const double *x, const double *t_centered, int64_t n, int d, const double *theta, void *stream,
-                       const ExternalFactor *ext, gpx_handle **out)
+                       const ExternalFactor *ext, gpx_handle **out, const double *Kmat = nullptr)
 {
     gpx_handle *h = new (std::nothrow) gpx_handle();
     if (!h) { gpx_set_error("out of host memory"); return GPX_ERR_HIP; }
     h->device = g_device;
-    int rc = parse_theta(theta, d, &h->v, &h->vt, h->w);
-    if (rc) { delete h; return rc; }
-    memcpy(h->theta, theta, sizeof(double) * (d + 2));
+    int rc = 0;
+    if (!Kmat) {
+        rc = parse_theta(theta, d, &h->v, &h->vt, h->w);
+        if (rc) { delete h; return rc; }
+        memcpy(h->theta, theta, sizeof(double) * (d + 2));
+    } else d = 0;
     h->n = n;
     h->d = d;
     h->npad = round_up(n, TILE);
@@ -511,8 +523,8 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
 
     double sw[GPX_MAX_D];
     for (int k = 0; k < d; ++k) sw[k] = sqrt(h->w[k]);
-    if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, d)) ||
-        (rc = dalloc(&h->wdev, d)) || (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) ||
+    if ((rc = dalloc(&h->x, n * d)) || (rc = dalloc(&h->xs_w, h->npad * d)) || (rc = dalloc(&h->sw, std::max(d, 1))) ||
+        (rc = dalloc(&h->wdev, std::max(d, 1))) || (rc = dalloc(&h->t, h->npad)) || (rc = dalloc(&h->y, h->npad)) ||
         (rc = dalloc(&h->alpha, h->npad)) || (rc = dalloc(&h->small, 4096 + h->npad)))
         return fail(rc);
     h->small_elems = 4096 + h->npad;
@@ -532,14 +544,19 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
     }
 #define FIT_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { gpx_set_error("%s failed: %s", #call, hipGetErrorString(e_)); return fail(GPX_ERR_HIP); } } while (0)
     FIT_HIP(hipMemsetAsync(h->info_dev, 0, sizeof(int) * (16 + 2 * h->nblk), s));
-    FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
-    FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
-    FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    if (Kmat) {
+        if ((rc = dalloc(&h->Ksrc, n * n))) return fail(rc);
+        FIT_HIP(hipMemcpyAsync(h->Ksrc, Kmat, sizeof(double) * n * n, hipMemcpyDefault, s));
+    } else {
+        FIT_HIP(hipMemcpyAsync(h->x, x, sizeof(double) * n * d, hipMemcpyDefault, s));
+        FIT_HIP(hipMemcpyAsync(h->sw, sw, sizeof(double) * d, hipMemcpyHostToDevice, s));
+        FIT_HIP(hipMemcpyAsync(h->wdev, h->w, sizeof(double) * d, hipMemcpyHostToDevice, s));
+    }
     FIT_HIP(hipMemsetAsync(h->t, 0, sizeof(double) * h->npad, s));
     FIT_HIP(hipMemcpyAsync(h->t, t_centered, sizeof(double) * n, hipMemcpyDefault, s));
     FIT_HIP(hipStreamSynchronize(s));   // sw is a stack buffer: its copy must be complete before any return path
     if (!ext) chol_probe_streams(s, h->s_pan, h->s_top);   // while every stream of the fit is idle (cached per pair of streams)
-    if ((rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
+    if (!Kmat && (rc = launch_scale_rows(h->x, n, h->npad, d, h->sw, h->xs_w, s))) return fail(rc);
 
     if (!ext) {
         // A stalled hand-off (an in-kernel wait of the look-ahead schedule expired: streams that were probed as concurrent no longer
@@ -561,11 +578,11 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
             return 0;
         };
         int info = 0;
-        if ((rc = factor(h->vt, &info))) return fail(rc);
+        if ((rc = factor(Kmat ? 0.0 : h->vt, &info))) return fail(rc);
         if (info > 0) {
             // reference fallback: cholesky(K + 1e-5 I)   (skgpuppy/Covariance.py:180-185)
             h->jitter = 1e-5;
-            if ((rc = factor(h->vt + h->jitter, &info))) return fail(rc);
+            if ((rc = factor((Kmat ? 0.0 : h->vt) + h->jitter, &info))) return fail(rc);
             if (info > 0) {
                 gpx_set_error("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter", info);
                 return fail(info);
@@ -579,6 +596,7 @@ static int make_handle(const double *x, const double *t_centered, int64_t n, int
     }
     FIT_HIP(hipStreamSynchronize(s));
 #undef FIT_HIP
+    if (h->Ksrc) { dfree(h->Ksrc); h->Ksrc = nullptr; }   // the factor replaces it
     *out = h;
     return 0;
 }
@@ -603,10 +621,26 @@ extern "C" int gpx_adopt_factor(const double *x, const double *t_centered, int64
     return make_handle(x, t_centered, n, d, theta, stream, &ext, out);
 }
 
+// ---- operator interface with a SUPPLIED matrix: what GaussianProcess.__init__ / estimate_many do for ANY Covariance subclass
+// (skgpuppy/GaussianProcess.py:39-41, :68-80 talk to cov.cov_matrix / cov.cov_matrix_ij / cov.inv_cov_matrix only; the base-class
+// inv_cov_matrix skgpuppy/Covariance.py:167-187 inverts whatever cov_matrix returns, with the +1e-5 I retry) -------------------------
+extern "C" int gpx_fit_matrix(const double *K, const double *t_centered, int64_t n, void *stream, gpx_handle **out)
+{
+    if (out) *out = nullptr;
+    GPX_TRY(gpx_require_device());
+    if (!K || !t_centered || !out || n < 1) { gpx_set_error("gpx_fit_matrix: null pointer or n < 1"); return GPX_ERR_BAD_ARG; }
+    return make_handle(nullptr, t_centered, n, 0, nullptr, stream, nullptr, out, K);
+}
+
 #define CHECK_H(h)                                                  \
     do {                                                            \
         if (!(h)) { gpx_set_error("null handle"); return GPX_ERR_BAD_ARG; } \
         GPX_HIP(hipSetDevice((h)->device));                         \
+    } while (0)
+// entry points that evaluate the GaussianCovariance kernel need the handle's inputs and theta: not a gpx_fit_matrix handle
+#define NEED_KERNEL(h, what)                                                                                             \
+    do {                                                                                                                 \
+        if ((h)->d == 0) { gpx_set_error(what ": the handle was built from a supplied matrix (gpx_fit_matrix): no inputs / theta to evaluate the kernel on"); return GPX_ERR_STATE; } \
     } while (0)
 
 extern "C" int gpx_n(const gpx_handle *h, int64_t *n, int *d)
@@ -639,11 +673,10 @@ extern "C" int gpx_logdet(gpx_handle *h, double *logdet)
 }
 
 // ---- predict -----------------------------------------------------------------------------------
-extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *mean_out, double *var_out)
+// xs != nullptr: the cross-covariance rows come from the Gram kernel (gpx_predict); otherwise kv [m, n] is the caller's
+// (gpx_predict_kv) and kdiag [m] the prior variance of each query (the diagonal of cov_matrix(x_star), GaussianProcess.py:75)
+static int predict_common(gpx_handle *h, const double *xs, const double *kv, const double *kdiag, int64_t m, double *mean_out, double *var_out)
 {
-    CHECK_H(h);
-    if (m < 0 || (m > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
-    if (m == 0) return 0;
     hipStream_t s = h->stream;
     const int d = h->d;
     int64_t cap = ((int64_t)8 << 30) / (h->npad * (int64_t)sizeof(double));   // rows per 8 GB buffer (two of them: Z and Zs)
@@ -652,24 +685,33 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
     const int64_t chunk = std::min<int64_t>(round_up(m, TILE), cap);
     GPX_TRY(ensure_Z(h, chunk));
     // the triangular solve runs out of place against the inverted diagonal squares (tsolve.hip): second slab-major buffer
-    double *xq = nullptr, *xqw = nullptr, *mv = nullptr, *Zs = nullptr;
+    double *xq = nullptr, *xqw = nullptr, *mv = nullptr, *Zs = nullptr, *kd = nullptr;
     GPX_TRY(dalloc(&Zs, chunk * h->npad));
     int rc = 0;
-    if ((rc = dalloc(&xq, chunk * d)) || (rc = dalloc(&xqw, chunk * d)) || (rc = dalloc(&mv, 2 * chunk))) {
-        dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw);
+    if ((rc = dalloc(&xq, chunk * std::max(d, 1))) || (rc = dalloc(&xqw, chunk * std::max(d, 1))) || (rc = dalloc(&mv, 2 * chunk)) || (rc = dalloc(&kd, chunk))) {
+        dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw); if (mv) dfree(mv);
         return rc;
     }
     for (int64_t m0 = 0; m0 < m && rc == 0; m0 += chunk) {
         const int64_t mc = std::min<int64_t>(chunk, m - m0), mp = round_up(mc, TILE);
-        hipError_t e = hipMemcpyAsync(xq, xs + m0 * d, sizeof(double) * mc * d, hipMemcpyDefault, s);
-        if (e != hipSuccess) { gpx_set_error("copy xs failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
-        if ((rc = launch_scale_rows(xq, mc, mp, d, h->sw, xqw, s))) break;
-        // kv = cross-covariance (no vt), zero padded: rows >= mc and columns >= n are 0
-        if ((rc = launch_gram(xqw, mc, h->xs_w, h->n, d, h->v, 0.0, 0, 1, h->Z, h->npad, mp, h->npad, s, &h->prof))) break;
+        hipError_t e = hipSuccess;
+        if (xs) {
+            e = hipMemcpyAsync(xq, xs + m0 * d, sizeof(double) * mc * d, hipMemcpyDefault, s);
+            if (e != hipSuccess) { gpx_set_error("copy xs failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
+            if ((rc = launch_scale_rows(xq, mc, mp, d, h->sw, xqw, s))) break;
+            // kv = cross-covariance (no vt), zero padded: rows >= mc and columns >= n are 0
+            if ((rc = launch_gram(xqw, mc, h->xs_w, h->n, d, h->v, 0.0, 0, 1, h->Z, h->npad, mp, h->npad, s, &h->prof))) break;
+        } else {
+            // the operator's own cross-covariance rows, zero padded to the tile grid
+            e = hipMemsetAsync(h->Z, 0, sizeof(double) * mp * h->npad, s);
+            if (e == hipSuccess) e = hipMemcpy2DAsync(h->Z, sizeof(double) * h->npad, kv + m0 * h->n, sizeof(double) * h->n, sizeof(double) * h->n, mc, hipMemcpyDefault, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(kd, kdiag + m0, sizeof(double) * mc, hipMemcpyDefault, s);
+            if (e != hipSuccess) { gpx_set_error("copy kv / kdiag failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
+        }
         // Z <- kv L^-T  : row m of Z is (L^-1 kv_m)^T
         if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof))) break;
-        // var = v + vt - |z|^2 ; mean = z . y   (k includes vt: GaussianProcess.py:75,78)
-        if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof))) break;
+        // var = k_mm - |z|^2 (k_mm = v + vt for the built-in kernel: k includes vt, GaussianProcess.py:75,78) ; mean = z . y
+        if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof, xs ? nullptr : kd))) break;
         e = hipMemcpyAsync(mean_out + m0, mv, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipMemcpyAsync(var_out + m0, mv + chunk, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -680,7 +722,28 @@ extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *m
     dfree(xq);
     dfree(xqw);
     dfree(mv);
+    dfree(kd);
     return rc;
+}
+
+extern "C" int gpx_predict(gpx_handle *h, const double *xs, int64_t m, double *mean_out, double *var_out)
+{
+    CHECK_H(h);
+    NEED_KERNEL(h, "gpx_predict");
+    if (m < 0 || (m > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (m == 0) return 0;
+    return predict_common(h, xs, nullptr, nullptr, m, mean_out, var_out);
+}
+
+// estimate_many for ANY operator (skgpuppy/GaussianProcess.py:68-80): kv = cov.cov_matrix_ij(x_star, x) [m, n] and
+// kdiag = diag(cov.cov_matrix(x_star)) [m] come from the caller; mean_out = kv alpha (WITHOUT meant), var_out = kdiag - |L^-1 kv^T|^2.
+// Works on every handle (gpx_fit and gpx_fit_matrix).
+extern "C" int gpx_predict_kv(gpx_handle *h, const double *kv, int64_t m, const double *kdiag, double *mean_out, double *var_out)
+{
+    CHECK_H(h);
+    if (m < 0 || (m > 0 && (!kv || !kdiag || !mean_out || !var_out))) { gpx_set_error("gpx_predict_kv: bad arguments"); return GPX_ERR_BAD_ARG; }
+    if (m == 0) return 0;
+    return predict_common(h, nullptr, kv, kdiag, m, mean_out, var_out);
 }
 
 // ---- accessors -----------------------------------------------------------------------------------
@@ -878,6 +941,7 @@ static int prepare_u(gpx_handle *h, const double *u)
 extern "C" int gpx_cjh(gpx_handle *h, const double *u, double *C, double *J, double *H)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_cjh");
     if (!u) { gpx_set_error("null u"); return GPX_ERR_BAD_ARG; }
     const int64_t n = h->n;
     const int d = h->d;
@@ -906,6 +970,7 @@ extern "C" int gpx_propagate_approx(gpx_handle *h, const double *u, const double
                                     double *sigma2, double *rest)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_approx");
     if (!u || !Sigma) { gpx_set_error("null u / Sigma"); return GPX_ERR_BAD_ARG; }
     const int d = h->d;
     const int64_t np = h->npad;
@@ -953,6 +1018,7 @@ extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const d
                                          double *partial_out)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_approx_rows");
     if (!u || !Sigma || !partial_out || row0 < 0 || row1 < row0 || row1 > h->n || (row0 % TILE && row0 != h->n) || (row1 % TILE && row1 != h->n)) {
         gpx_set_error("gpx_propagate_approx_rows: bad arguments (rows [%ld, %ld) of %ld)", (long)row0, (long)row1, (long)h->n);
         return GPX_ERR_BAD_ARG;
@@ -1004,6 +1070,7 @@ extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const d
 extern "C" int gpx_propagate_approx_rhs(gpx_handle *h, const double *u, const double *Sigma, int k0, int k1, double *partial_out)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_approx_rhs");
     if (!u || !Sigma || !partial_out || k0 < 0 || k1 < k0 || k1 > h->d + 1) {
         gpx_set_error("gpx_propagate_approx_rhs: bad arguments (vectors [%d, %d) of %d)", k0, k1, h->d + 1);
         return GPX_ERR_BAD_ARG;
@@ -1054,6 +1121,7 @@ extern "C" int gpx_propagate_approx_rhs(gpx_handle *h, const double *u, const do
 extern "C" int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_dvh");
     if (!u || !dvh_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     const int d = h->d;
     const int64_t np = h->npad;
@@ -1185,6 +1253,7 @@ extern "C" int gpx_propagate_exact_rows(gpx_handle *h, const double *u, const do
                                         double *partial_out)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_exact_rows");
     if (!u || !Sigma || !partial_out || row0 < 0 || row1 < row0 || row1 > h->n || (row0 % TILE && row0 != h->n) || (row1 % TILE && row1 != h->n)) {
         gpx_set_error("gpx_propagate_exact_rows: bad arguments (rows [%ld, %ld) of %ld)", (long)row0, (long)row1, (long)h->n);
         return GPX_ERR_BAD_ARG;
@@ -1200,6 +1269,7 @@ extern "C" int gpx_propagate_exact_rows(gpx_handle *h, const double *u, const do
 extern "C" int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, double *mean, double *var)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_propagate_exact");
     if (!u || !Sigma) { gpx_set_error("null u / Sigma"); return GPX_ERR_BAD_ARG; }
     return exact_common(h, u, Sigma, true, mean, var);
 }
@@ -1207,6 +1277,7 @@ extern "C" int gpx_propagate_exact(gpx_handle *h, const double *u, const double 
 extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_exact_mean");
     if (!u || !Sigma || !mean) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     return exact_common(h, u, Sigma, false, mean, nullptr);
 }
@@ -1214,11 +1285,11 @@ extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigm
 // ---- a4 with a caller-supplied matrix: Covariance.inv_cov_matrix(x, theta, cov_matrix=K) = inv(K)
 // (skgpuppy/Covariance.py:186-187).  K must be symmetric positive definite (it is a covariance matrix); it is
 // Cholesky-factored on the GPU, status > 0 when it is not.
-__global__ __launch_bounds__(256) void pad_copy_kernel(const double *K, long n, double *L, long npad)
+__global__ __launch_bounds__(256) void pad_copy_kernel(const double *K, long n, double *L, long npad, double add_diag)
 {
     const long i = blockIdx.x;
     for (long j = threadIdx.x; j < npad; j += 256)
-        L[i * npad + j] = (i < n && j < n) ? K[i * n + j] : ((i == j) ? 1.0 : 0.0);
+        L[i * npad + j] = (i < n && j < n) ? K[i * n + j] + ((i == j) ? add_diag : 0.0) : ((i == j) ? 1.0 : 0.0);
 }
 
 extern "C" int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, double *logdet_out)
@@ -1239,7 +1310,7 @@ extern "C" int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, dou
         if ((e = hipMalloc((void **)&info, sizeof(int))) != hipSuccess) break;
         if ((e = hipMemsetAsync(info, 0, sizeof(int), s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(Kd, K, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
-        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)npad), dim3(256), 0, s, (const double *)Kd, (long)n, L, (long)npad);
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)npad), dim3(256), 0, s, (const double *)Kd, (long)n, L, (long)npad, 0.0);
         if ((rc = chol_factor(L, npad, nblk, Dinv, diag, info, s, nullptr, nullptr, nullptr))) break;
         if ((e = hipMemcpyAsync(&info_h, info, sizeof(int), hipMemcpyDeviceToHost, s)) != hipSuccess) break;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) break;
@@ -1282,6 +1353,7 @@ extern "C" int gpx_nll(gpx_handle *h, double *nll)
 extern "C" int gpx_nll_grad(gpx_handle *h, double *grad_out)
 {
     CHECK_H(h);
+    NEED_KERNEL(h, "gpx_nll_grad");
     if (!grad_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     GPX_TRY(ensure_kinv(h));
     const int d = h->d;
@@ -1305,6 +1377,98 @@ extern "C" int gpx_nll_grad(gpx_handle *h, double *grad_out)
     g[1] = 0.5 * h->vt * o[dm + 1];                      // dK/dtheta_1 = vt I          (Covariance.py:505-510)
     for (int k = 0; k < d; ++k) g[2 + k] = -0.25 * o[1 + k];   // dK/dtheta_{2+k} = -1/2 Kf w_k dx_k^2 (:643-657); w_k is in the scaled inputs
     GPX_HIP(hipMemcpy(grad_out, g.data(), sizeof(double) * (d + 2), hipMemcpyDefault));
+    return 0;
+}
+
+// d nll / d theta_j for ANY operator from its derivative matrix dK = d cov_matrix / d theta_j [n, n] (Covariance._d_nll_d_theta,
+// skgpuppy/Covariance.py:266-282): 1/2 tr(K^-1 dK) - 1/2 alpha^T dK alpha as ONE pass over K^-1 and dK (K^-1 from the factor is
+// exactly symmetric, so tr(K^-1 dK) = sum_ij Kinv_ij dK_ij); one wave per row, per-row partials, fixed-order final sum.
+__global__ __launch_bounds__(256) void trace_quad_rows_kernel(const double *__restrict__ Kinv, long ldk, const double *__restrict__ dK, long n,
+                                                             const double *__restrict__ alpha, double *__restrict__ part)
+{
+    const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    double s1 = 0.0, s2 = 0.0;
+    for (long j = lane; j < n; j += 64) {
+        const double dk = dK[i * n + j];
+        s1 = fma(Kinv[i * ldk + j], dk, s1);
+        s2 = fma(dk, alpha[j], s2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { part[2 * i] = s1; part[2 * i + 1] = alpha[i] * s2; }
+}
+__global__ __launch_bounds__(256) void sum_pairs_kernel(const double *__restrict__ part, long n, double *__restrict__ out)
+{
+    __shared__ double r1[256], r2[256];
+    double a = 0.0, b = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    r1[threadIdx.x] = a; r2[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = r1[0]; out[1] = r2[0]; }
+}
+
+extern "C" int gpx_nll_grad_matrix(gpx_handle *h, const double *dK, double *grad_out)
+{
+    CHECK_H(h);
+    if (!dK || !grad_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    GPX_TRY(ensure_kinv(h));
+    hipStream_t s = h->stream;
+    const int64_t n = h->n;
+    double *dKd = nullptr, *part = nullptr;
+    GPX_TRY(dalloc(&dKd, n * n));
+    int rc = dalloc(&part, 2 * n + 2);
+    if (rc) { dfree(dKd); return rc; }
+    double o[2] = {0.0, 0.0};
+    hipError_t e = hipMemcpyAsync(dKd, dK, sizeof(double) * n * n, hipMemcpyDefault, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(trace_quad_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, (const double *)h->Kinv, (long)h->npad,
+                           (const double *)dKd, (long)n, (const double *)h->alpha, part);
+        hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, (const double *)part, (long)n, part + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(o, part + 2 * n, sizeof(double) * 2, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    else (void)hipStreamSynchronize(s);
+    dfree(dKd);
+    dfree(part);
+    GPX_HIP(e);
+    const double g = 0.5 * o[0] - 0.5 * o[1];
+    GPX_HIP(hipMemcpy(grad_out, &g, sizeof(double), hipMemcpyDefault));
+    return 0;
+}
+
+// out[r] = M V[r] for a SUPPLIED symmetric matrix M [n, n] and a few vectors V [nrhs, n] (rows): the reference's quadratic-form
+// helpers take an explicit Kinv argument (UncertaintyPropagationApprox._get_sigma2 / _get_variance_rest,
+// skgpuppy/UncertaintyPropagation.py:412-481); when it is not the fitted model's own this is the device route for it.
+extern "C" int gpx_symv(const double *M, int64_t n, const double *V, int nrhs, double *out)
+{
+    GPX_TRY(gpx_require_device());
+    if (!M || !V || !out || n < 1 || nrhs < 1 || nrhs > 64) { gpx_set_error("gpx_symv: bad arguments (n=%ld, nrhs=%d; at most 64 vectors)", (long)n, nrhs); return GPX_ERR_BAD_ARG; }
+    const int64_t npad = round_up(n, TILE);
+    hipStream_t s = nullptr;
+    double *Md = nullptr, *Mp = nullptr, *Vd = nullptr, *KVd = nullptr;
+    int rc = 0;
+    hipError_t e = hipSuccess;
+    do {
+        if ((rc = dalloc(&Md, n * n)) || (rc = dalloc(&Mp, npad * npad)) || (rc = dalloc(&Vd, (int64_t)nrhs * npad)) || (rc = dalloc(&KVd, (int64_t)nrhs * npad))) break;
+        if ((e = hipMemcpyAsync(Md, M, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
+        hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)npad), dim3(256), 0, s, (const double *)Md, (long)n, Mp, (long)npad, 0.0);   // (identity padding meets zero-padded vectors)
+        if ((e = hipMemsetAsync(Vd, 0, sizeof(double) * nrhs * npad, s)) != hipSuccess) break;
+        if ((e = hipMemcpy2DAsync(Vd, sizeof(double) * npad, V, sizeof(double) * n, sizeof(double) * n, nrhs, hipMemcpyDefault, s)) != hipSuccess) break;
+        if ((rc = launch_kinv_pass(Mp, npad, npad, nrhs, Vd, KVd, s, nullptr))) break;
+        if ((e = hipMemcpy2DAsync(out, sizeof(double) * n, KVd, sizeof(double) * npad, sizeof(double) * n, nrhs, hipMemcpyDefault, s)) != hipSuccess) break;
+        e = hipStreamSynchronize(s);
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    dfree(Md); dfree(Mp); dfree(Vd); dfree(KVd);
+    if (rc) return rc;
+    GPX_HIP(e);
     return 0;
 }
 

@@ -122,7 +122,8 @@ struct gpx_handle {
     hipStream_t s_pan = nullptr;   // side stream (high priority) for the latency-bound diagonal chain
     hipStream_t s_top = nullptr;   // pipelined panel solves of the factorisation (chol.hip, TopPipe)
 
-    double *x = nullptr;        // [n, d] raw inputs
+    double *Ksrc = nullptr;     // gpx_fit_matrix only, during the fit: the supplied matrix [n, n] (kept for the jitter retry)
+    double *x = nullptr;        // [n, d] raw inputs (d == 0: a handle built from a supplied matrix)
     double *xs_w = nullptr;     // [npad, d] inputs scaled by sqrt(w) (rows >= n are zero)
     double *sw = nullptr;       // [d] sqrt(w) on device
     double *wdev = nullptr;     // [d] w on device
@@ -210,7 +211,7 @@ int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const doub
 int build_linv_t(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);
 int launch_predict_reduce(const double *Z, int64_t ldz, int64_t m, int64_t npad, const double *y, double vplusvt,
-                          double *mean, double *var, hipStream_t s, Profiler *prof);
+                          double *mean, double *var, hipStream_t s, Profiler *prof, const double *kdiag = nullptr);
 int launch_set_identity(double *Z, int64_t ld, int64_t n, hipStream_t s);
 int launch_symmetrize_lower(double *A, int64_t ld, int64_t n, hipStream_t s);
 

@@ -18,9 +18,93 @@ def tracedot(A, B):
     return np.dot(np.ravel(np.asarray(A).T), np.ravel(B))
 
 
+class _MatrixModel(object):
+    """Owner of one gpx_handle built from a SUPPLIED covariance matrix (gpx_fit_matrix): the device route of the generic operator
+    interface -- Cholesky factor of the operator's own cov_matrix(x, theta) (+1e-5 I retry), alpha, lazily K^-1."""
+
+    def __init__(self, K, t_centered):
+        K = _gpx.f64(K)
+        if K.ndim != 2 or K.shape[0] != K.shape[1]:
+            raise ValueError("cov_matrix must return a square matrix, got shape %r" % (K.shape,))
+        self.n, self.d = K.shape[0], 0
+        t = np.zeros(self.n) if t_centered is None else _gpx.f64(t_centered)
+        if t.shape != (self.n,):
+            raise ValueError("t must have %d entries" % self.n)
+        self._h = ctypes.c_void_p()
+        _gpx.check(_gpx.lib.gpx_fit_matrix(_gpx.ptr(K), _gpx.ptr(t), self.n, None, ctypes.byref(self._h)), "gpx_fit_matrix")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("device model already released")
+        return self._h
+
+    def close(self, _free=_gpx.lib.gpx_free, _null=ctypes.c_void_p):
+        if getattr(self, "_h", None):
+            _free(self._h)
+            self._h = _null()
+
+    __del__ = close
+
+    def predict_kv(self, kv, kdiag):
+        kv = _gpx.f64(np.atleast_2d(kv))
+        kdiag = _gpx.f64(np.atleast_1d(kdiag))
+        m = kv.shape[0]
+        if kv.shape[1] != self.n or kdiag.shape != (m,):
+            raise ValueError("kv must be (m, %d) and kdiag (m,)" % self.n)
+        mean = np.empty(m)
+        var = np.empty(m)
+        _gpx.check(_gpx.lib.gpx_predict_kv(self.handle, _gpx.ptr(kv), m, _gpx.ptr(kdiag), _gpx.ptr(mean), _gpx.ptr(var)), "gpx_predict_kv")
+        return mean, var
+
+    def alpha(self):
+        out = np.empty(self.n)
+        _gpx.check(_gpx.lib.gpx_alpha(self.handle, _gpx.ptr(out)), "gpx_alpha")
+        return out
+
+    def solve(self, B):
+        B = _gpx.f64(np.atleast_2d(B))
+        kb = np.empty_like(B)
+        _gpx.check(_gpx.lib.gpx_solve(self.handle, _gpx.ptr(B), B.shape[0], None, _gpx.ptr(kb)), "gpx_solve")
+        return kb
+
+    def kinv(self):
+        out = np.empty((self.n, self.n))
+        _gpx.check(_gpx.lib.gpx_kinv(self.handle, _gpx.ptr(out)), "gpx_kinv")
+        return out
+
+    def logdet(self):
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_logdet(self.handle, ctypes.byref(v)), "gpx_logdet")
+        return v.value
+
+    def nll(self):
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_nll(self.handle, ctypes.byref(v)), "gpx_nll")
+        return v.value
+
+    def nll_grad_entry(self, dK):
+        dK = _gpx.f64(dK)
+        if dK.shape != (self.n, self.n):
+            raise ValueError("_d_cov_matrix_d_theta must return an (%d, %d) matrix" % (self.n, self.n))
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_nll_grad_matrix(self.handle, _gpx.ptr(dK), ctypes.byref(v)), "gpx_nll_grad_matrix")
+        return v.value
+
+    def jitter(self):
+        v = ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_jitter_used(self.handle, ctypes.byref(v)), "gpx_jitter_used")
+        return v.value
+
+
 class Covariance(object):
-    """Superclass for all covariance functions (skgpuppy/Covariance.py:111-359): the interface
-    GaussianProcess talks to."""
+    """Superclass for all covariance functions (skgpuppy/Covariance.py:111-359): the interface GaussianProcess talks to.
+
+    As in the reference the base class is GENERIC: a subclass that implements `__call__` (and `get_theta` for the ML fit)
+    gets cov_matrix_ij / cov_matrix from it, and inv_cov_matrix, the likelihood and its gradient from those -- the matrix-sized
+    algebra (factorisation with the +1e-5 I retry, inverse, log det, quadratic forms, trace terms) runs on the GPU on the
+    operator's own matrices (gpx_fit_matrix and friends); only the entry-wise evaluation of a user's Python kernel is host work,
+    as it is in the reference."""
 
     def __init__(self):
         pass
@@ -32,13 +116,34 @@ class Covariance(object):
         raise NotImplementedError
 
     def cov_matrix_ij(self, xi, xj, theta):
-        raise NotImplementedError
+        """N1 x N2 matrix of the operator's own scalar kernel (Covariance.py:137-152)"""
+        ni, nj = len(xi), len(xj)
+        K = np.zeros((ni, nj))
+        for i in range(ni):
+            for j in range(nj):
+                K[i, j] = self(xi[i], xj[j], theta)
+        return K
 
     def cov_matrix(self, x, theta):
+        # (Covariance.py:155-164)
         return self.cov_matrix_ij(x, x, theta)
 
     def inv_cov_matrix(self, x, theta, cov_matrix=None):
-        raise NotImplementedError
+        """inverse of the operator's own cov_matrix(x, theta), or of `cov_matrix` when given (Covariance.py:167-187).  The reference
+        LU-inverts and falls back to chol(K + 1e-5 I) when that raises; here K is Cholesky-factored on the GPU with the same
+        single +1e-5 I retry and K^-1 = L^-T L^-1."""
+        if cov_matrix is not None:
+            K = _gpx.f64(cov_matrix)
+            if K.ndim != 2 or K.shape[0] != K.shape[1]:
+                raise ValueError("cov_matrix must be square")
+            out = np.empty_like(K)
+            _gpx.check(_gpx.lib.gpx_spd_inverse(_gpx.ptr(K), K.shape[0], _gpx.ptr(out), None), "gpx_spd_inverse")
+            return out
+        model = _MatrixModel(np.array(self.cov_matrix(x, theta)), None)
+        try:
+            return model.kinv()
+        finally:
+            model.close()
 
     def get_Hessian(self, u, xi, theta):
         raise NotImplementedError
@@ -47,14 +152,26 @@ class Covariance(object):
         raise NotImplementedError
 
     # ---- hyper-parameter maximum likelihood ("next" row f1; skgpuppy/Covariance.py:189-337) ----------------
+    def _matrix_model_at(self, x, t, theta):
+        """device model of the operator's own cov_matrix(x, theta) with targets t, kept for the next call at the same theta
+        (L-BFGS-B asks for the value and the gradient one after the other)"""
+        th = np.array(theta, dtype=float)
+        ta = None if t is None else _gpx.f64(t)
+        key = (id(x), np.shape(x), None if ta is None else ta.tobytes(), th.tobytes())
+        cached = getattr(self, "_mm_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if cached is not None:
+            cached[1].close()
+        self._mm_cache = None
+        model = _MatrixModel(np.array(self.cov_matrix(x, theta)), ta)
+        self._mm_cache = (key, model)
+        return model
+
     def _log_det_cov_matrix(self, x, theta):
         """log det of cov_matrix(x, theta) (Covariance.py:189-195: numpy slogdet); here 2 sum log diag of its Cholesky factor,
         computed on the GPU from the operator's own matrix"""
-        K = _gpx.f64(self.cov_matrix(x, theta))
-        out = np.empty_like(K)
-        ld = ctypes.c_double()
-        _gpx.check(_gpx.lib.gpx_spd_inverse(_gpx.ptr(K), K.shape[0], _gpx.ptr(out), ctypes.byref(ld)), "gpx_spd_inverse")
-        return ld.value
+        return self._matrix_model_at(x, None, theta).logdet()
 
     def _d_cov_d_theta(self, xi, xj, theta, j):
         """central difference of the scalar kernel in theta_j, eps = 1e-5 (Covariance.py:219-233)"""
@@ -77,10 +194,18 @@ class Covariance(object):
         return self._d_cov_matrix_d_theta_ij(x, x, theta, j)
 
     def _negativeloglikelihood(self, x, t, theta):
-        raise NotImplementedError
+        """N/2 log 2pi + 1/2 log det K + 1/2 t^T K^-1 t for the operator's own K (Covariance.py:197-216): factorisation, log det and
+        the quadratic form on the GPU; 1e20 when K cannot be factored, like the reference's except branch."""
+        try:
+            return self._matrix_model_at(x, t, theta).nll()
+        except (np.linalg.LinAlgError, RuntimeWarning, ZeroDivisionError, ValueError):
+            return 1.0e+20
 
     def _d_nll_d_theta(self, x, t, theta):
-        raise NotImplementedError
+        """gradient of the NLL from the operator's own derivative matrices (Covariance.py:266-282): entry j is
+        1/2 tr(K^-1 dK_j) - 1/2 alpha^T dK_j alpha, one fused device pass over K^-1 and dK_j each"""
+        model = self._matrix_model_at(x, t, theta)
+        return np.array([model.nll_grad_entry(self._d_cov_matrix_d_theta(x, theta, j)) for j in range(len(theta))])
 
     def _nll_function(self, x, t):
         # (Covariance.py:284-297)
@@ -108,6 +233,11 @@ class Covariance(object):
         theta_min = fmin_l_bfgs_b(func, theta_start, bounds=None, approx_grad=False, fprime=fprime)
         return np.array(theta_min[0])
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_mm_cache", None)     # device handles never enter a pickle
+        return state
+
 
 def _theta(theta, d):
     th = _gpx.f64(theta)
@@ -118,7 +248,20 @@ def _theta(theta, d):
 
 class GaussianCovariance(Covariance):
     """ARD squared-exponential kernel, theta = (log v, log vt, log w_1..w_d)
-    (skgpuppy/Covariance.py:435-689)."""
+    (skgpuppy/Covariance.py:435-689).
+
+    The matrix methods are the fused HIP path (Gram kernel, Cholesky on the Gram tiles, one-pass likelihood gradient).  A user
+    subclass that overrides one of the matrix builders keeps the reference's semantics -- cov_matrix is cov_matrix_ij + vt I,
+    inv_cov_matrix / the likelihood / its gradient are built on whatever those return -- by falling back to the generic
+    device route of `Covariance` (`_fused()` decides per instance)."""
+
+    _MATRIX_METHODS = ("cov_matrix_ij", "cov_matrix", "inv_cov_matrix", "_d_cov_matrix_d_theta", "_d_cov_matrix_d_theta_ij",
+                       "_log_det_cov_matrix")
+
+    def _fused(self):
+        """True when every matrix-defining method of this instance is GaussianCovariance's own"""
+        cls = type(self)
+        return cls is GaussianCovariance or all(getattr(cls, m) is getattr(GaussianCovariance, m) for m in self._MATRIX_METHODS)
 
     def __call__(self, xi, xj, theta):
         # scalar kernel incl. the "+vt iff xi == xj elementwise" hack (Covariance.py:440-451)
@@ -161,18 +304,15 @@ class GaussianCovariance(Covariance):
         """cov_matrix_ij(x, x) + vt I (Covariance.py:461-464); the diagonal add is fused in the kernel."""
         with np.errstate(divide="ignore"):
             vt = float(np.exp(theta[1]))
+        if type(self).cov_matrix_ij is not GaussianCovariance.cov_matrix_ij:     # a subclass's own cross-covariance
+            return np.asarray(self.cov_matrix_ij(x, x, theta), dtype=float) + vt * np.eye(np.shape(x)[0])
         return self._gram(x, x, theta, vt)
 
     def inv_cov_matrix(self, x, theta, cov_matrix=None):
         """K^-1 (Covariance.py:167-187).  The reference LU-inverts; here K is Cholesky-factored on the GPU
         (with the reference's +1e-5 I retry on a non-PD pivot) and K^-1 = L^-T L^-1."""
-        if cov_matrix is not None:
-            K = _gpx.f64(cov_matrix)
-            if K.ndim != 2 or K.shape[0] != K.shape[1]:
-                raise ValueError("cov_matrix must be square")
-            out = np.empty_like(K)
-            _gpx.check(_gpx.lib.gpx_spd_inverse(_gpx.ptr(K), K.shape[0], _gpx.ptr(out), None), "gpx_spd_inverse")
-            return out
+        if cov_matrix is not None or not self._fused():
+            return Covariance.inv_cov_matrix(self, x, theta, cov_matrix)
         from .GaussianProcess import _DeviceModel
         xa = _gpx.f64(x)
         model = _DeviceModel(xa, np.zeros(xa.shape[0]), _theta(theta, xa.shape[1]))
@@ -183,6 +323,8 @@ class GaussianCovariance(Covariance):
 
     def _log_det_cov_matrix(self, x, theta):
         """log det (K + vt I) (Covariance.py:189-195) from the Cholesky factor of a device fit"""
+        if not self._fused():
+            return Covariance._log_det_cov_matrix(self, x, theta)
         from .GaussianProcess import _DeviceModel
         xa = _gpx.f64(x)
         model = _DeviceModel(xa, np.zeros(xa.shape[0]), _theta(theta, xa.shape[1]))
@@ -223,7 +365,8 @@ class GaussianCovariance(Covariance):
         b = _gpx.f64(xj)
         if j == 1:
             return np.zeros((a.shape[0], b.shape[0]))
-        K = np.asarray(Cov, dtype=float) if Cov is not None else self.cov_matrix_ij(a, b, theta)
+        # (the reference recomputes the built-in Gram inline here, :622-633 -- also for a subclass with its own cov_matrix_ij)
+        K = np.asarray(Cov, dtype=float) if Cov is not None else GaussianCovariance.cov_matrix_ij(self, a, b, theta)
         if j == 0:
             return K
         w = np.exp(np.asarray(theta[2:], dtype=float))
@@ -250,6 +393,8 @@ class GaussianCovariance(Covariance):
     def _negativeloglikelihood(self, x, t, theta):
         """N/2 log 2pi + 1/2 log det K + 1/2 t^T K^-1 t on the GPU (Covariance.py:197-216); 1e20 when K cannot be
         factored, like the reference's except branch."""
+        if not self._fused():
+            return Covariance._negativeloglikelihood(self, x, t, theta)
         try:
             model = self._model_at(x, t, theta)
             out = ctypes.c_double()
@@ -261,13 +406,15 @@ class GaussianCovariance(Covariance):
     def _d_nll_d_theta(self, x, t, theta):
         """gradient of the NLL (Covariance.py:266-282 with the derivative Grams of :505-512, :605-657): one fused
         pass over K^-1 on the GPU instead of 2+d derivative matrices."""
+        if not self._fused():
+            return Covariance._d_nll_d_theta(self, x, t, theta)
         model = self._model_at(x, t, theta)
         g = np.empty(len(theta))
         _gpx.check(_gpx.lib.gpx_nll_grad(model.handle, _gpx.ptr(g)), "gpx_nll_grad")
         return g
 
     def __getstate__(self):
-        state = dict(self.__dict__)
+        state = Covariance.__getstate__(self)
         state.pop("_ml_cache", None)     # device handles never enter a pickle
         return state
 
@@ -472,7 +619,7 @@ class SPGPCovariance(Covariance):
         return self._fit_model(x, t, theta).nll_grad()
 
     def __getstate__(self):
-        state = dict(self.__dict__)
+        state = Covariance.__getstate__(self)
         state.pop("_cross_model", None)          # device handles never enter a pickle
         state.pop("_fit_cache", None)
         return state

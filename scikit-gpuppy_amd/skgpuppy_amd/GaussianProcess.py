@@ -10,7 +10,7 @@ import ctypes
 import numpy as np
 
 from . import _gpx
-from .Covariance import GaussianCovariance, SPGPCovariance
+from .Covariance import GaussianCovariance, SPGPCovariance, _MatrixModel
 
 
 class _DeviceModel(object):
@@ -114,14 +114,27 @@ class GaussianProcess(object):
         self._fit()
 
     # ---- device model management -----------------------------------------------------------
+    def _route(self):
+        """which device path serves this operator.  The reference's GaussianProcess talks to `cov` only through its interface
+        (GaussianProcess.py:39-41, :75-78); here the two built-in kernels have fused paths and EVERY other operator -- a
+        from-scratch Covariance, or a subclass of a built-in one that overrides a matrix builder -- takes the generic route:
+        its own cov_matrix / cov_matrix_ij, factored and solved on the GPU (gpx_fit_matrix / gpx_predict_kv)."""
+        cov = self.cov
+        if type(cov) is SPGPCovariance:
+            return "spgp"
+        if isinstance(cov, GaussianCovariance) and cov._fused():
+            return "gaussian"
+        return "generic"
+
     def _fit(self):
-        if isinstance(self.cov, SPGPCovariance):
+        route = self._route()
+        if route == "spgp":
             # low-rank fit: no N x N matrix (the reference's own "TODO Optimize for the SPGP covariance function")
             self._model = self.cov._model(self.x, self.t, self.theta_min)
-            return
-        if not isinstance(self.cov, GaussianCovariance):
-            raise TypeError("only GaussianCovariance and SPGPCovariance are on the accelerated path")
-        self._model = _DeviceModel(_gpx.f64(self.x), _gpx.f64(self.t), _gpx.f64(self.theta_min))
+        elif route == "gaussian":
+            self._model = _DeviceModel(_gpx.f64(self.x), _gpx.f64(self.t), _gpx.f64(self.theta_min))
+        else:
+            self._model = _MatrixModel(np.array(self.cov.cov_matrix(self.x, self.theta_min)), self.t)
 
     def _dev(self):
         if self._model is None:
@@ -187,21 +200,44 @@ class GaussianProcess(object):
     def estimate_many(self, x_stars):
         """(GaussianProcess.py:68-80): mean + meant and diag(k - kv Kinv kv^T) for M query points --
         cross-covariance, multi-RHS triangular solve and row reductions on the GPU, no M x M matrix."""
+        if self._route() == "generic":
+            return self._estimate_many_generic(np.array(x_stars))
         xs = _gpx.f64(np.array(x_stars))
         if xs.ndim != 2 or xs.shape[1] != self.d:
             raise ValueError("x_stars must be (m, %d)" % self.d)
         mean, var = self._dev().predict(xs)
         return mean + self.meant, var
 
+    def _estimate_many_generic(self, x_star, chunk=2048):
+        """(GaussianProcess.py:68-80) for any operator: kv = cov.cov_matrix_ij(x_star, x) and the DIAGONAL of
+        k = cov.cov_matrix(x_star) come from the operator itself (k in row chunks: its off-diagonal entries are never used),
+        the solve against the factor and the row reductions run on the GPU (gpx_predict_kv)."""
+        m = len(x_star)
+        mean = np.empty(m)
+        var = np.empty(m)
+        for m0 in range(0, m, chunk):
+            xc = x_star[m0:m0 + chunk]
+            kdiag = np.diag(np.asarray(self.cov.cov_matrix(xc, self.theta_min), dtype=float)).copy()
+            kv = self.cov.cov_matrix_ij(xc, self.x, self.theta_min)
+            mean[m0:m0 + chunk], var[m0:m0 + chunk] = self._dev().predict_kv(kv, kdiag)
+        return mean + self.meant, var
+
     def estimate(self, x_star):
         """(GaussianProcess.py:94-111): single-point twin of estimate_many."""
+        if self._route() == "generic":
+            # k = cov(x*, x*), kv = cov.cov_matrix_ij([x*], x)  (GaussianProcess.py:104-108)
+            x_star = np.array(x_star)
+            k = self.cov(x_star, x_star, self.theta_min)
+            kv = self.cov.cov_matrix_ij(np.atleast_2d(x_star), self.x, self.theta_min)
+            mean, var = self._dev().predict_kv(kv, [k])
+            return mean[0] + self.meant, var[0]
         xs = _gpx.f64(np.atleast_2d(np.array(x_star)))
         mean, var = self._dev().predict(xs)
         return mean[0] + self.meant, var[0]
 
     def _get_beta(self):
         # beta = K^-1 t (GaussianProcess.py:114-119)
-        if isinstance(self.cov, SPGPCovariance):
+        if self._route() == "spgp":
             return np.dot(self.Kinv, self.t)
         return self._dev().alpha()
 

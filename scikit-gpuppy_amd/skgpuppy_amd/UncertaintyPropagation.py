@@ -38,7 +38,13 @@ def _u_sigma(gp, u, Sigma_x):
 
 class UncertaintyPropagationApprox(UncertaintyPropagationGA):
     """Girard's approximate Gaussian-approximation moments (UncertaintyPropagation.py:386-630 /
-    UncertaintyPropagation2.pyx:189-380)."""
+    UncertaintyPropagation2.pyx:189-380).
+
+    With the built-in GaussianCovariance everything runs fused on the device handle (C / J / tr built by a kernel, one pass
+    K^-1 [C, J_1..J_d] or two sweeps over the factor, dot products).  With any other operator (the generic route of
+    GaussianProcess) C_ux / J_ux / H_ux come from the operator's own __call__ / get_Jacobian / get_Hessian -- 3N host calls,
+    as in the reference (:504-510) -- and the reference's N^2 double loops become two device sweeps over the factor
+    (gpx_solve) plus O(N d) dot products."""
 
     def __init__(self, gp):
         UncertaintyPropagationGA.__init__(self, gp)
@@ -46,12 +52,22 @@ class UncertaintyPropagationApprox(UncertaintyPropagationGA):
         self.Winv = self.gp._get_W_inv()
         self.u = None
         self._cjh = None
+        self._kv = None            # generic route: K^-1 [C, J_1..J_d] of the cached u
 
-    def _parts(self, u, Sigma_x):
-        uu, S = _u_sigma(self.gp, u, Sigma_x)
+    def _generic(self):
+        return self.gp._route() != "gaussian"
+
+    def _new_u(self, u, uu):
         if self.u is None or (np.asarray(self.u) != uu).any():
             self.u = u               # stored by reference like UncertaintyPropagation.py:500
             self._cjh = None
+            self._kv = None
+
+    def _parts(self, u, Sigma_x):
+        uu, S = _u_sigma(self.gp, u, Sigma_x)
+        self._new_u(u, uu)
+        if self._generic():
+            return self._parts_generic(S)
         out = [ctypes.c_double() for _ in range(4)]
         st = _gpx.lib.gpx_propagate_approx(self.gp._dev().handle, _gpx.ptr(uu), _gpx.ptr(S),
                                            *[ctypes.byref(o) for o in out])
@@ -59,11 +75,46 @@ class UncertaintyPropagationApprox(UncertaintyPropagationGA):
         mean, var, sigma2, rest = [o.value for o in out]
         return mean, var, sigma2, rest
 
+    # ---- generic operators ---------------------------------------------------------------------------------------
+    def _kinv_rows(self):
+        """K^-1 [C, J_1..J_d] for the cached u: two sweeps over the factor on the device"""
+        if self._kv is None:
+            C, J, _H = self._fetch_cjh()
+            self._kv = self.gp._dev().solve(np.vstack([C[None, :], J[:, :, 0].T]))
+        return self._kv
+
+    @staticmethod
+    def _quadratic_parts(cuu, beta, C, J, H, S, KC, KJ, Ktr=None):
+        """(mean without meant, sigma2, variance2 + variance3) from the vectors and their products with K^-1
+        (UncertaintyPropagation.py:397-408, :412-433, :435-481); KC = Kinv C, KJ[k] = Kinv J_k, Ktr = Kinv tr (None: Kinv is
+        symmetric, C.Ktr = tr.KC)"""
+        trace = np.einsum("iab,ba->i", H, S)                    # tracedot(H_i, Sigma_x)
+        mean = np.dot(beta, C) + 0.5 * np.dot(beta, trace)
+        sigma2 = cuu - np.dot(C, KC)
+        sd = np.diag(S)
+        var2 = -sum(sd[k] * (np.dot(J[:, k, 0], KJ[k]) - np.dot(beta, J[:, k, 0]) ** 2) for k in range(len(sd)))
+        var3 = -np.dot(trace, KC) if Ktr is None else -0.5 * (np.dot(C, Ktr) + np.dot(trace, KC))
+        return mean, sigma2, var2 + var3
+
+    def _parts_generic(self, S):
+        C, J, H = self._fetch_cjh()
+        kv = self._kinv_rows()
+        mean, sigma2, rest = self._quadratic_parts(self.gp._covariance(self.u, self.u), self.gp._get_beta(), C, J, H, S, kv[0], kv[1:])
+        return mean, sigma2 + rest, sigma2, rest
+
     def _fetch_cjh(self):
         if self._cjh is None:
             if self.u is None:
                 raise AttributeError("C_ux/J_ux/H_ux exist only after a propagate call (as in the reference)")
             gp = self.gp
+            if self._generic():
+                # (UncertaintyPropagation.py:504-510): the operator's own scalar kernel, Jacobian and Hessian per training point
+                x, u = gp.x, self.u
+                n = len(x)
+                self._cjh = (np.array([gp._covariance(u, x[i]) for i in range(n)], dtype=float),
+                             np.array([gp._get_Jacobian(u, x[i]) for i in range(n)], dtype=float).reshape(n, gp.d, 1),
+                             np.array([gp._get_Hessian(u, x[i]) for i in range(n)], dtype=float))
+                return self._cjh
             uu = _gpx.f64(self.u)
             C = np.empty(gp.n)
             J = np.empty((gp.n, gp.d))
@@ -95,21 +146,56 @@ class UncertaintyPropagationApprox(UncertaintyPropagationGA):
         mean, var, _s2, _rest = self._parts(u, Sigma_x)
         return np.float64(mean + self.gp._get_mean_t()), np.float64(var)
 
-    # The three quadratic-form helpers of the reference (UncertaintyPropagation.py:412-488 / UncertaintyPropagation2.pyx:221-299).
-    # There they loop over explicit Kinv / x / beta / C_ux / J_ux / H_ux arrays -- always the fitted GP's own and the caches of
-    # the last propagation.  Here the sums come from the device cache of `u` (one pass K^-1 [C, J_1..J_d], then dot products);
-    # the array arguments are accepted for signature parity and not read.
+    # The three quadratic-form helpers of the reference (UncertaintyPropagation.py:412-488 / UncertaintyPropagation2.pyx:221-299)
+    # take explicit Kinv / x / beta / C_ux / J_ux / H_ux arrays.  Called the way the reference itself calls them -- with the fitted
+    # GP's own Kinv and the caches of the last propagation (or with nothing) -- the sums come from the device cache of `u`.  Any
+    # OTHER array is honoured: the vectors are taken from the arguments and their products with the explicit matrix run on the
+    # device (gpx_symv), so a caller that passes a different Kinv gets that Kinv's numbers, as in the reference.
+    def _is_own(self, Kinv=None, beta=None, C_ux=None, J_ux=None, H_ux=None):
+        gp = self.gp
+        cj = self._cjh if self._cjh is not None else (None, None, None)
+        return ((Kinv is None or Kinv is gp._Kinv) and beta is None and (C_ux is None or C_ux is cj[0]) and
+                (J_ux is None or J_ux is cj[1]) and (H_ux is None or H_ux is cj[2]))
+
+    def _explicit_parts(self, u, Sigma_x, Kinv, beta, C_ux, J_ux, H_ux):
+        gp = self.gp
+        uu, S = _u_sigma(gp, u, Sigma_x)
+        self._new_u(u, uu)
+        C = np.asarray(C_ux if C_ux is not None else self.C_ux, dtype=float).reshape(gp.n)
+        J = np.asarray(J_ux if J_ux is not None else self.J_ux, dtype=float).reshape(gp.n, gp.d, 1)
+        H = np.asarray(H_ux if H_ux is not None else self.H_ux, dtype=float).reshape(gp.n, gp.d, gp.d)
+        b = np.asarray(beta if beta is not None else gp._get_beta(), dtype=float).reshape(gp.n)
+        trace = np.einsum("iab,ba->i", H, S)
+        V = _gpx.f64(np.vstack([C[None, :], trace[None, :], J[:, :, 0].T]))
+        if Kinv is None or Kinv is gp._Kinv:
+            KV = gp._dev().solve(V)                              # the model's own K^-1: two sweeps over its factor
+        else:
+            M = _gpx.f64(Kinv)
+            if M.shape != (gp.n, gp.n):
+                raise ValueError("Kinv must be (%d, %d)" % (gp.n, gp.n))
+            KV = np.empty_like(V)
+            _gpx.check(_gpx.lib.gpx_symv(_gpx.ptr(M), gp.n, _gpx.ptr(V), V.shape[0], _gpx.ptr(KV)), "gpx_symv")
+        return self._quadratic_parts(gp._covariance(u, u), b, C, J, H, S, KV[0], KV[2:], KV[1])
+
     def _get_sigma2(self, u, Kinv=None, x=None, C_ux=None, J_ux=None, H_ux=None):
         """C(u,u) - C^T K^-1 C  (UncertaintyPropagation.py:412-433); needs no Sigma_x"""
-        return self._parts(u, np.zeros((self.gp.d, self.gp.d)))[2]
+        Z = np.zeros((self.gp.d, self.gp.d))
+        if self._is_own(Kinv, None, C_ux, J_ux, H_ux):
+            return self._parts(u, Z)[2]
+        return self._explicit_parts(u, Z, Kinv, None, C_ux, J_ux, H_ux)[1]
 
     def _get_variance_rest(self, u, Sigma_x, Kinv=None, x=None, beta=None, C_ux=None, J_ux=None, H_ux=None):
         """variance2 + variance3  (UncertaintyPropagation.py:435-481)"""
-        return self._parts(u, Sigma_x)[3]
+        if self._is_own(Kinv, beta, C_ux, J_ux, H_ux):
+            return self._parts(u, Sigma_x)[3]
+        return self._explicit_parts(u, Sigma_x, Kinv, beta, C_ux, J_ux, H_ux)[2]
 
     def _get_sigma2_and_variance_rest(self, u, Sigma_x, Kinv=None, x=None, beta=None):
         """(UncertaintyPropagation.py:483-488)"""
-        _m, _var, sigma2, rest = self._parts(u, Sigma_x)
+        if self._is_own(Kinv, beta):
+            _m, _var, sigma2, rest = self._parts(u, Sigma_x)
+            return sigma2, rest
+        _m, sigma2, rest = self._explicit_parts(u, Sigma_x, Kinv, beta, None, None, None)
         return sigma2, rest
 
     def _getFactor(self, u, Sigma_x, v):
@@ -120,9 +206,13 @@ class UncertaintyPropagationApprox(UncertaintyPropagationGA):
     def _get_variance_dv_h(self, u, h):
         # (UncertaintyPropagation.py:564-630); all d values come out of one device call
         uu = _gpx.f64(u)
-        if self.u is None or (np.asarray(self.u) != uu).any():
-            self.u = u
-            self._cjh = None
+        self._new_u(u, uu)
+        if self._generic():
+            C, J, H = self._fetch_cjh()
+            kv = self._kinv_rows()
+            beta = self.gp._get_beta()
+            v2 = -(np.dot(J[:, h, 0], kv[1 + h]) - np.dot(beta, J[:, h, 0]) ** 2)
+            return v2 - np.dot(kv[0], H[:, h, h])
         out = np.empty(self.gp.d)
         st = _gpx.lib.gpx_propagate_dvh(self.gp._dev().handle, _gpx.ptr(uu), _gpx.ptr(out))
         _gpx.check(st, "gpx_propagate_dvh")
@@ -162,8 +252,15 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
             self._prepare_C_corr(len(u))
             self._prepare_C_corr2(len(u))
 
+    def _need_builtin(self):
+        if self.gp._route() != "gaussian":
+            raise NotImplementedError("UncertaintyPropagationExact is Girard's closed form for the ARD squared-exponential kernel: it needs "
+                                      "a GaussianProcess on the built-in GaussianCovariance (UncertaintyPropagationApprox serves any operator "
+                                      "with get_Jacobian / get_Hessian)")
+
     def propagate_mean(self, u, Sigma_x, C_ux=None):
         # C_ux is accepted for signature parity (UncertaintyPropagation.py:269); it is rebuilt on device
+        self._need_builtin()
         self._set_constants(u, np.asarray(Sigma_x, dtype=float))
         uu, S = _u_sigma(self.gp, u, Sigma_x)
         out = ctypes.c_double()
@@ -173,6 +270,7 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
 
     def propagate_GA(self, u, Sigma_x):
         # (UncertaintyPropagation.py:323-379)
+        self._need_builtin()
         uu, S = _u_sigma(self.gp, u, Sigma_x)
         self._set_constants(uu, S)
         mean, var = ctypes.c_double(), ctypes.c_double()

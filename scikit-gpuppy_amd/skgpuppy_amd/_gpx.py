@@ -40,6 +40,10 @@ SIGNATURES = {
     "gpx_pool_trim": (_int, []),
     "gpx_gram": (_int, [_dp, _i64, _dp, _i64, _int, _dp, _dbl, _dp]),
     "gpx_fit": (_int, [_dp, _dp, _i64, _int, _dp, ctypes.c_void_p, ctypes.POINTER(_hp)]),
+    "gpx_fit_matrix": (_int, [_dp, _dp, _i64, ctypes.c_void_p, ctypes.POINTER(_hp)]),
+    "gpx_predict_kv": (_int, [_hp, _dp, _i64, _dp, _dp, _dp]),
+    "gpx_nll_grad_matrix": (_int, [_hp, _dp, ctypes.POINTER(_dbl)]),
+    "gpx_symv": (_int, [_dp, _i64, _dp, _int, _dp]),
     "gpx_free": (None, [_hp]),
     "gpx_n": (_int, [_hp, ctypes.POINTER(_i64), ctypes.POINTER(_int)]),
     "gpx_jitter_used": (_int, [_hp, ctypes.POINTER(_dbl)]),

@@ -221,3 +221,41 @@ def test_oracle_derivative_grams_against_reference_vectors():
             np.testing.assert_allclose(orc.d_gram_d_theta(x, th, j), want, rtol=1e-10, atol=1e-13 * np.abs(want).max() + 1e-300)
         og = orc.OracleGP(x, np.zeros(len(x)), th)
         assert abs(og.logdet() - float(g[name + "__logdet"])) < 1e-8 * max(1.0, abs(float(g[name + "__logdet"])))
+
+
+# ------------------------------------------------------------------------------------------------
+# the GENERIC operator interface of the oracle (OracleCovariance / OracleOperatorGP) against the genuine reference's base classes
+# ------------------------------------------------------------------------------------------------
+def test_generic_operator_oracle_against_reference_golden():
+    from _operators import make_rational_quadratic, make_warped_gaussian
+    g = load_golden("generic_ops")
+    # (A) from-scratch operator: only __call__ / get_theta
+    cov = make_rational_quadratic(orc.OracleCovariance)()
+    x, t, xs, th = g["rq_x"], g["rq_t"], g["rq_xs"], g["rq_theta"]
+    np.testing.assert_allclose(cov.cov_matrix(x, th), g["rq_K"], rtol=1e-13)
+    gp = orc.OracleOperatorGP(x, t, cov, th)
+    np.testing.assert_allclose(gp.Kinv, g["rq_Kinv"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(gp.beta(), g["rq_beta"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(cov._negativeloglikelihood(x, gp.t, th), g["rq_nll"], rtol=1e-12)
+    np.testing.assert_allclose(cov._log_det_cov_matrix(x, th), g["rq_logdet"], rtol=1e-12)
+    np.testing.assert_allclose(cov._d_nll_d_theta(x, gp.t, th), g["rq_grad"], rtol=1e-8, atol=1e-9)
+    m, v = gp.estimate_many(xs)
+    np.testing.assert_allclose(m, g["rq_pred_mean"], rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(v, g["rq_pred_var"], rtol=1e-8, atol=1e-11)
+    np.testing.assert_allclose(gp.estimate(xs[0]), g["rq_est0"], rtol=1e-8, atol=1e-11)
+    # (B) GaussianCovariance subclass with its own cov_matrix_ij
+    cov = make_warped_gaussian(orc.OracleGaussianCovariance)()
+    x, t, xs, th = g["wg_x"], g["wg_t"], g["wg_xs"], g["wg_theta"]
+    np.testing.assert_allclose(cov.cov_matrix(x, th), g["wg_K"], rtol=1e-12)
+    gp = orc.OracleOperatorGP(x, t, cov, th)
+    np.testing.assert_allclose(gp.Kinv, g["wg_Kinv"], rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(cov._negativeloglikelihood(x, gp.t, th), g["wg_nll"], rtol=1e-11)
+    np.testing.assert_allclose(cov._d_nll_d_theta(x, gp.t, th), g["wg_grad"], rtol=1e-7, atol=1e-8)
+    m, v = gp.estimate_many(xs)
+    np.testing.assert_allclose(m, g["wg_pred_mean"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(v, g["wg_pred_var"], rtol=1e-7, atol=1e-10)
+    u, S = g["wg_u"], g["wg_Sigma"]
+    cache = gp.cjh(u)
+    np.testing.assert_allclose(orc.approx_propagate(gp, u, S, cache), g["wg_approx"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose([orc.approx_dvh(gp, u, h, cache) for h in range(3)], g["wg_dvh"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(orc.approx_factor(gp, u, S, 0.02, cache), g["wg_factor"], rtol=1e-8)

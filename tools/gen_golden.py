@@ -209,7 +209,92 @@ def spgp_cases():
     return out
 
 
+def generic_operator_cases():
+    """The operator interface with operators that are NOT the built-in kernel (plug-in seam #1): (A) a
+    from-scratch subclass of the reference's Covariance that implements only __call__ / get_theta -- everything else is the
+    reference's generic base class (Covariance.py:137-282) and GaussianProcess (GaussianProcess.py:19-111); (B) a subclass of the
+    reference's GaussianCovariance with its own cov_matrix_ij.  Inputs AND outputs are stored; the operators are re-stated in the
+    tests (they are test inputs, not reference code)."""
+    _install_shims()
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    from skgpuppy.Covariance import Covariance, GaussianCovariance
+    from skgpuppy.GaussianProcess import GaussianProcess
+    import skgpuppy.UncertaintyPropagation as UP
+    out = {}
+
+    class RationalQuadratic(Covariance):
+        """k = v (1 + r^2 / (2 a l^2))^-a + vt [xi == xj],  theta = log (v, vt, l, a)"""
+        def __call__(self, xi, xj, theta):
+            v, vt, ell, a = np.exp(theta)
+            diff = np.asarray(xi, dtype=float) - np.asarray(xj, dtype=float)
+            r2 = np.dot(diff, diff)
+            return v * (1.0 + r2 / (2.0 * a * ell * ell)) ** (-a) + (vt if (np.asarray(xi) == np.asarray(xj)).all() else 0.0)
+
+        def get_theta(self, x, t):
+            return np.log(np.array([np.var(t), np.var(t) / 4, 1.0, 1.0]))
+
+    rng = np.random.RandomState(4242)
+    n, d, m = 60, 2, 15
+    x = rng.uniform(0, 6, (n, d))
+    t = np.sin(x[:, 0]) * np.cos(0.7 * x[:, 1]) + 0.05 * rng.randn(n)
+    xs = rng.uniform(0, 6, (m, d))
+    theta = np.log(np.array([1.3, 0.02, 1.7, 0.8]))
+    cov = RationalQuadratic()
+    gp = GaussianProcess(x, t, cov, theta.copy())
+    out["rq_x"], out["rq_t"], out["rq_xs"], out["rq_theta"] = x, t, xs, theta
+    out["rq_K"] = cov.cov_matrix(x, theta)
+    out["rq_Kinv"] = np.array(gp.Kinv)
+    out["rq_nll"] = np.float64(cov._negativeloglikelihood(x, gp.t, theta))
+    out["rq_grad"] = np.array(cov._d_nll_d_theta(x, gp.t, theta))
+    out["rq_logdet"] = np.float64(cov._log_det_cov_matrix(x, theta))
+    out["rq_pred_mean"], out["rq_pred_var"] = gp.estimate_many(xs)
+    out["rq_est0"] = np.array(gp.estimate(xs[0]))
+    out["rq_beta"] = np.array(gp._get_beta())
+
+    class WarpedGaussian(GaussianCovariance):
+        """GaussianCovariance whose cross-covariance is modulated by the (positive definite) factor 1 + 0.1 cos(xi_0 - xj_0)"""
+        def cov_matrix_ij(self, xi, xj, theta):
+            K = GaussianCovariance.cov_matrix_ij(self, xi, xj, theta)
+            a = np.asarray(xi, dtype=float)[:, 0][:, None]
+            b = np.asarray(xj, dtype=float)[:, 0][None, :]
+            return K * (1.0 + 0.1 * np.cos(a - b))
+
+    n, d, m = 120, 3, 20
+    x = rng.uniform(0, 10, (n, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(n)
+    xs = rng.uniform(0, 10, (m, d))
+    theta = np.log(np.array([2.0, 0.01, 0.04, 0.05, 0.03]))
+    cov = WarpedGaussian()
+    gp = GaussianProcess(x, t, cov, theta.copy())
+    out["wg_x"], out["wg_t"], out["wg_xs"], out["wg_theta"] = x, t, xs, theta
+    out["wg_K"] = cov.cov_matrix(x, theta)
+    out["wg_Kinv"] = np.array(gp.Kinv)
+    out["wg_nll"] = np.float64(cov._negativeloglikelihood(x, gp.t, theta))
+    out["wg_grad"] = np.array(cov._d_nll_d_theta(x, gp.t, theta))
+    out["wg_pred_mean"], out["wg_pred_var"] = gp.estimate_many(xs)
+    out["wg_est0"] = np.array(gp.estimate(xs[0]))
+    u = np.array([5.0, 4.5, 5.5])
+    S = np.array([[0.02, 0.004, 0.0], [0.004, 0.03, -0.002], [0.0, -0.002, 0.01]])
+    up = UP.UncertaintyPropagationApprox(gp)
+    out["wg_u"], out["wg_Sigma"] = u, S
+    out["wg_approx"] = np.array(up.propagate_GA(u, S))
+    out["wg_dvh"] = np.array([up._get_variance_dv_h(u, h) for h in range(d)])
+    out["wg_factor"] = np.float64(up._getFactor(u, S, 0.02))
+    # the quadratic-form helpers with an EXPLICIT Kinv that is not the GP's own (UncertaintyPropagation.py:412-481)
+    K2inv = np.linalg.inv(out["wg_K"] + 0.05 * np.eye(n))
+    out["wg_K2inv"] = K2inv
+    out["wg_sigma2_K2"] = np.float64(up._get_sigma2(u, K2inv, gp.x, up.C_ux, up.J_ux, up.H_ux))
+    out["wg_rest_K2"] = np.float64(up._get_variance_rest(u, S, K2inv, gp.x, gp._get_beta(), up.C_ux, up.J_ux, up.H_ux))
+    return out
+
+
 def main():
+    if "--generic" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        np.savez_compressed(os.path.join(OUT, "generic_ops.npz"), **generic_operator_cases())
+        print("generic_ops.npz")
+        return
     if "--spgp" in sys.argv:
         os.makedirs(OUT, exist_ok=True)
         np.savez_compressed(os.path.join(OUT, "spgp.npz"), **spgp_cases())
