@@ -252,6 +252,12 @@ int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t 
  * of the column solves (the look-ahead order of the single-GPU factorisation). */
 int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, const double *prev, int64_t ldp,
                             int64_t kp, double *dinv, double *diag, int *info_dev, void *stream);
+/* the factorisation (first_block = 0) or its trailing part (all updates from the block columns before first_block applied; first_block
+ * a multiple of 8) as ONE persistent dataflow launch (csrc/dflow.hip): leaf, column solves, in-panel and trailing updates are tasks that
+ * resident workgroups hand to each other through agent-scope counters instead of ~24 dependent launches per 1024-column panel.  This is what
+ * gpx_fit runs for the trailing panels of its Cholesky (replaces skgpuppy/Covariance.py:179); exported for tests and probes.  Synchronous.
+ * info_dev: two device ints, zero before the call: [0] potrf status (1-based failing column), [1] set when an in-kernel wait expired. */
+int gpx_dev_chol_dataflow(double *L, int64_t ld, int64_t nblk, int64_t first_block, double *dinv, double *diag, int *info_dev, void *stream);
 /* build a handle around an EXISTING factor in HBM (L [npad,npad] with ld == npad, dinv [npad/128,128,128],
  * diag [npad]; the caller keeps ownership and must keep them alive): solves for alpha; predict / propagate as usual.
  * The strictly-upper 128x128 tiles of L_dev are scratch for the library (the first Approx propagation stores L^T there).

@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -167,6 +168,14 @@ static int chol_rec(double *L, int64_t ld, int64_t b0, int64_t b1, double *Dinv,
 // updates): see skgpuppy_amd/distributed.py.
 // ------------------------------------------------------------------------------------------------
 constexpr int64_t CHOL_NBP = 8;
+
+// dflow.hip: the trailing panels as one persistent dataflow kernel
+int64_t chol_dataflow_state_ints(int64_t nbr);
+int64_t chol_dataflow_table_ints(int64_t nbr);
+bool chol_dataflow_supported(int64_t nbr);
+int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s);
+
 static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 
 // factor block columns [B0,B1) of the rows >= B0 (all updates from columns < B0 already applied)
@@ -454,6 +463,13 @@ void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top)
     stream_release(s_blk, blocker_stream_prio());
 }
 
+// default hand-over panel of the dataflow kernel for a factorisation of P outer panels (P on error / off)
+static int64_t dflow_default_from(int64_t P)
+{
+    static const int tail = [] { const char *e = getenv("GPX_DFLOW_TAIL"); return e ? atoi(e) : 0; }();   // 0: off (until the default is tuned)
+    return tail > 0 ? std::max<int64_t>(0, P - tail) : P;
+}
+
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
                 hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork,
                 const std::function<int(int64_t, int64_t, bool)> *panel_final)
@@ -470,6 +486,28 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     while (Bs.back() < nblk) Bs.push_back(std::min<int64_t>(nblk, Bs.back() + CHOL_NBP));
     const int64_t P = (int64_t)Bs.size() - 1;
     auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
+    // First outer panel that the persistent dataflow kernel (dflow.hip) takes over: from there on the launch-per-step chain is the
+    // critical path (every 128-column step costs ~100 us of dependent launches against ~50 us of work).  GPX_DFLOW_FROM = p (>= 0:
+    // panel index, < 0: panels from the end, "off": never).  Needs nothing of the multi-stream machinery.
+    int64_t pdf = P;
+    if (!g_force_plain) {
+        static const char *env = getenv("GPX_DFLOW_FROM");
+        int64_t want = dflow_default_from(P);
+        if (env) want = (env[0] == 'o') ? P : (atol(env) < 0 ? P + atol(env) : atol(env));
+        want = std::max<int64_t>(0, std::min<int64_t>(want, P));
+        if (want < P && chol_dataflow_supported(nblk - bnd(want))) pdf = want;
+    }
+    double *dfl_state = nullptr;
+    std::vector<int> dfl_tab;
+    if (pdf < P) {
+        const int64_t nbr = nblk - bnd(pdf);
+        GPX_TRY(dalloc(&dfl_state, (chol_dataflow_state_ints(nbr) + chol_dataflow_table_ints(nbr)) / 2 + 2));
+    }
+    auto run_dataflow = [&](int64_t p_first) -> int {
+        GPX_TRY(launch_chol_dataflow(L, ld, nblk, bnd(p_first), Dinv, diagL, info_dev, reinterpret_cast<int *>(dfl_state), dfl_tab, wait_limit_ticks(), s));
+        if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true));
+        return 0;
+    };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
@@ -533,6 +571,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, pure latency)
         // underneath all of that, and the third stream solves ALL rows below panel p's square column by column alongside
         // panel p's chain (TopPipe), so that neither a top slice nor a panel TRSM remains on the main stream.
+        if (pdf == 0) {   // the whole factorisation is the dataflow kernel's
+            if (after_fork) GPX_TRY((*after_fork)());
+            return run_dataflow(0);
+        }
         if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP), s));
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
@@ -566,6 +608,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // tiles that stay off them, fit 28.9 -> 28.1 ms)
                 GPX_TRY(reserve_now());
             }
+            const bool handover = (p + 1 == pdf);   // panel p + 1 and everything behind it belong to the dataflow kernel
             const int64_t K = (B1 - B0) * TILE;
             // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
             //     square before anything else so that the side stream starts early
@@ -579,11 +622,13 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_HIP(hipEventRecord(ev_next[p], s));
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
-            GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
-            // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
-            // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
-            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
-            if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
+            if (!handover) {
+                GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+                // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
+                // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
+                GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
+                if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
+            }
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
@@ -599,7 +644,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                            K, -1.0, 1.0, 0, s, prof));
-                if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
+                if (piped(p + 1) && !handover) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     if (merged == 0) {
                         // every column solve waits for its own column's narrow tiles (top_column).  Handing the count over as an event
                         // from a stream of its own was measured too: one more cross-stream edge per panel, fit +1.4 ms.
@@ -618,6 +663,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                                            (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
+            }
+            if (handover) {
+                release_blockers(s);
+                GPX_TRY(run_dataflow(p + 1));
+                break;
             }
             // work of the caller that rides along on the main stream, behind this panel's trailing update
             static const int hook_early = [] { const char *e = getenv("GPX_HOOK_EARLY"); return e ? atoi(e) : 1; }();
@@ -647,6 +697,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
+    if (dfl_state) dfree(dfl_state);
     return rc;
 }
 

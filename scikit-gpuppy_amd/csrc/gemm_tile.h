@@ -16,9 +16,14 @@ __device__ __forceinline__ const char *gpx_uniform_ptr(const char *p)
 // (the x128-wide forms keep one column tile per row block, which makes the in-place TRSM leaves safe).
 //
 // gemm_tile: one block tile (by, bx) of C over the contraction range [kstart, kend).  smem: two stages, 1024-aligned.
+// gemm_tile_x: the same with the accumulators held by the caller, so that a product can be continued after a wait (dflow.hip):
+// flags & GT_INIT: acc = (beta / alpha) C (or 0) first, else the incoming acc is continued; flags & GT_STORE: C = alpha acc at the end,
+// else acc is handed back.  kend <= kstart with neither flag is a no-op.
+enum { GT_INIT = 1, GT_STORE = 2 };
 template <int WM, int WN>
-__device__ __forceinline__ void gemm_tile(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int bx, int by,
-                                          long kstart, int kend, double alpha, double beta, double *smem, bool write_through = false)
+__device__ __forceinline__ void gemm_tile_x(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int bx, int by,
+                                            long kstart, int kend, double alpha, double beta, double *smem, bool write_through,
+                                            v4d (&acc)[WM][WN], int flags)
 {
     constexpr int BTM = 32 * WM, BTN = 32 * WN;   // block tile
     constexpr int WTM = 16 * WM, WTN = 16 * WN;   // wave tile
@@ -77,13 +82,14 @@ __device__ __forceinline__ void gemm_tile(const double *A, long lda, const doubl
     }
 
     const int nk = (kend - (int)kstart) / GEMM_BK;
-    GPX_DMA_STAGE(0, 0)
+    if (nk > 0) GPX_DMA_STAGE(0, 0)
     // C enters through the accumulators: acc0 = (beta/alpha) C, result = alpha (acc0 + A B^T).  The tile's read
     // overlaps the first DMA stage instead of sitting, dependent, in the epilogue (matters for the K = 128..512
     // updates on the factorisation's critical path).  accumulator register r of tile (i,j) is C[fq + 4r][fr].
     double *Cw = C + ((long)by * BTM + wr * WTM + fq) * ldc + (long)bx * BTN + wc * WTN + fr;
-    v4d acc[WM][WN];
-    if (beta != 0.0) {
+    if (!(flags & GT_INIT)) {
+        // continuation: the caller's accumulators as they stand
+    } else if (beta != 0.0) {
         const double bs = beta / alpha;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -133,7 +139,7 @@ __device__ __forceinline__ void gemm_tile(const double *A, long lda, const doubl
         _Pragma("unroll") for (int j_ = 0; j_ < WN; ++j_)                              \
             acc[i_][j_] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][i_], fb[SET][j_], acc[i_][j_], 0, 0, 0);
 
-    GPX_LOAD_FRAGS(0, 0, 0)
+    if (nk > 0) { GPX_LOAD_FRAGS(0, 0, 0) }
     {
         // two buffers, the stage loop unrolled by two: buffer offsets are immediates of the ds_read_b64 / M0 values, so the
         // steady state issues no vector instruction besides MFMAs, fragment reads and the DMA
@@ -166,6 +172,7 @@ __device__ __forceinline__ void gemm_tile(const double *A, long lda, const doubl
 #undef GPX_MMA
 #undef GPX_DMA_STAGE
 
+    if (!(flags & GT_STORE)) return;
     // epilogue: pure stores.  write_through (wave-uniform): the tile is handed to a consumer that starts before this launch ends
     // (gemm_nt_f64_trap_signal_kernel) -- its stores go straight through the XCD's L2 (sc1), so that publishing it needs no
     // write-back of the whole L2 underneath the other workgroups.
@@ -188,6 +195,14 @@ __device__ __forceinline__ void gemm_tile(const double *A, long lda, const doubl
 }
 
 
+
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_tile(const double *A, long lda, const double *B, long ldb, double *C, long ldc, int bx, int by,
+                                          long kstart, int kend, double alpha, double beta, double *smem, bool write_through = false)
+{
+    v4d acc[WM][WN];
+    gemm_tile_x<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem, write_through, acc, GT_INIT | GT_STORE);
+}
 
 // lid -> (by, bx) of a lower-only launch.  1-D grid over the needed tiles only.  Row by holds the tiles bx <= by + tri_off:
 // tri_off = 0 is the lower triangle of a square C; tri_off > 0 a trapezoid whose first tri_off tile columns are full.

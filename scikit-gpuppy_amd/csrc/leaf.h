@@ -3,6 +3,19 @@
 #pragma once
 #include "common.h"
 
+// PUB: the inverse is handed to other workgroups of the SAME launch (dflow.hip): every access of `dinv` is an agent-scope (sc1,
+// write-through / L1-bypassing) access, so that it needs no release fence; otherwise plain accesses (the consumer is a later launch)
+template <bool PUB> __device__ __forceinline__ void dinv_store(double *p, double v)
+{
+    if (PUB) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool PUB> __device__ __forceinline__ double dinv_load(const double *p)
+{
+    if (PUB) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+
 __device__ __forceinline__ double fast_rsqrt(double d)
 {
     double y = __builtin_amdgcn_rsq(d);        // v_rsq_f64: ~2^-26 relative
@@ -89,6 +102,7 @@ template <int S> __device__ __forceinline__ void leaf_inverse_level(double *X, i
 }
 
 // shared tail of the leaf variants: L -> global, then the inverse of the factor in place (recursive doubling over the 16-blocks)
+template <bool PUB = false>
 __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, double *diag_out, int *info, double *X, int *bad_sp)
 {
 #define bad_s (*bad_sp)
@@ -114,7 +128,7 @@ __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, do
     __syncthreads();
     for (int e = t; e < 8 * 256; e += 256) {
         const int b = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        X[xblk(b, b) + r * 17 + c] = dinv[(16 * b + r) * TILE + 16 * b + c];
+        X[xblk(b, b) + r * 17 + c] = dinv_load<PUB>(&dinv[(16 * b + r) * TILE + 16 * b + c]);
     }
     __syncthreads();
 
@@ -130,7 +144,7 @@ __device__ __forceinline__ void leaf_finish(double *A, long ld, double *dinv, do
         for (int bi = 0; bi < 8; ++bi)
 #pragma unroll
             for (int bj = 0; bj < 8; ++bj)
-                dinv[(16 * bi + r) * TILE + 16 * bj + c] = (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0;
+                dinv_store<PUB>(&dinv[(16 * bi + r) * TILE + 16 * bj + c], (bj <= bi) ? X[xblk(bi, bj) + r * 17 + c] : 0.0);
     }
     LEAF_STAMP(7);
     LEAF_STAMP_RT(9);
@@ -224,7 +238,7 @@ __device__ __forceinline__ void leaf_update_blocks(const double *X, const int (&
 // elimination of one panel: the group's copy of the diagonal block d, its row gi of the appended identity, and the rows b of
 // the wave's NB blocks below (accumulator layout = elimination layout: group fq holds rows fq + 4 r of a block); stores
 // L_ib, inv(L_d) (diagonal 16-block of dinv) and -- the first group of every wave -- a quarter of L_d
-template <int NB>
+template <int NB, bool PUB = false>
 __device__ __forceinline__ void leaf_panel_eliminate(double *X, double *dinv, int jb, const v4d (&acc)[2], const int (&ibs)[2], int wave, int fq,
                                                      int g, int c, int col_offset, int *bad_sp)
 {
@@ -244,7 +258,7 @@ __device__ __forceinline__ void leaf_panel_eliminate(double *X, double *dinv, in
     // a non-positive (or NaN) pivot: first such column of the first such panel
     const unsigned long long badm = __builtin_amdgcn_ballot_w64(!(piv > 0.0)) & 0xffffull;
     if (threadIdx.x == 0 && badm && *bad_sp == 0) *bad_sp = col_offset + 16 * jb + __builtin_ctzll(badm) + 1;
-    dinv[(16 * jb + c) * TILE + 16 * jb + g] = gi * sc;   // inv(L_d)[c][g]; exactly zero for c < g
+    dinv_store<PUB>(&dinv[(16 * jb + c) * TILE + 16 * jb + g], gi * sc);   // inv(L_d)[c][g]; exactly zero for c < g
 #pragma unroll
     for (int q = 0; q < NB; ++q) {
         double *Ob = &X[xblk(ibs[q], jb)];
@@ -258,6 +272,7 @@ __device__ __forceinline__ void leaf_panel_eliminate(double *X, double *dinv, in
     }
 }
 
+template <bool PUB = false>
 __device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv, double *diag_out, int *info, int col_offset,
                                                double *X, int *bad_sp)
 {
@@ -318,14 +333,14 @@ __device__ __forceinline__ void leaf_elim_body(double *A, long ld, double *dinv,
         LEAF_ACC2(3, 16 + jb);
         if (jb > 0) __syncthreads();
         LEAF_ACC2(3, 24 + jb);
-        if (nbw == 2) leaf_panel_eliminate<2>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
-        else if (nbw == 1) leaf_panel_eliminate<1>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
-        else leaf_panel_eliminate<0>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        if (nbw == 2) leaf_panel_eliminate<2, PUB>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        else if (nbw == 1) leaf_panel_eliminate<1, PUB>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
+        else leaf_panel_eliminate<0, PUB>(X, dinv, jb, acc, ibs, wave, fq, g, c, col_offset, bad_sp);
         LEAF_ACC2(2, 32 + jb);
         __syncthreads();
         LEAF_ACC2(2, 40 + jb);
     }
-    leaf_finish(A, ld, dinv, diag_out, info, X, bad_sp);
+    leaf_finish<PUB>(A, ld, dinv, diag_out, info, X, bad_sp);
 #undef bad_s
 }
 
