@@ -429,7 +429,8 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
     GPX_TRY(h->tri.forward_begin(h->t, h->npad, 1, s));
     int64_t pending = 0;                                       // first outer panel the substitution has not passed yet
     bool finished = false;
-    const std::function<int(int64_t, int64_t, bool)> ride = [&](int64_t p_final, int64_t slack, bool last) -> int {
+    const std::function<int(int64_t, int64_t, bool, hipStream_t)> ride = [&](int64_t p_final, int64_t slack, bool last, hipStream_t on) -> int {
+        hipStream_t s = on ? on : h->stream;   // (the factorisation may hand the pre-tail work to an idle stream of its own: chol.hip, dataflow hand-over)
         // slack = outer panels still to be updated.  The main stream idles underneath the chains of the last panels, but what it runs
         // there shares the chip with those chains (the forward updates stream the factor at HBM rate, the chain's small GEMMs slow
         // down: chains of 0.7-0.8 ms grew to 0.9-1.1 ms when the catching-up started with four panels left, and the fit gained
@@ -475,7 +476,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
         };
         GPX_TRY(chol_factor(h->L, h->npad, h->nblk, h->Dinv, h->diagL, h->info_dev, s, h->s_pan, &h->prof, h->s_top, &rest, &ride));
     }
-    GPX_TRY(ride(h->tri.P - 1, 0, true));                      // whatever the factorisation's schedule left over
+    GPX_TRY(ride(h->tri.P - 1, 0, true, nullptr));                      // whatever the factorisation's schedule left over
     GPX_HIP(hipMemcpyAsync(info_host, h->info_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
     return 0;

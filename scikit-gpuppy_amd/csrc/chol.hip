@@ -472,13 +472,13 @@ static int64_t dflow_default_from(int64_t P)
 
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev, hipStream_t s,
                 hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork,
-                const std::function<int(int64_t, int64_t, bool)> *panel_final)
+                const std::function<int(int64_t, int64_t, bool, hipStream_t)> *panel_final)
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr) {
         if (after_fork) GPX_TRY((*after_fork)());
         GPX_TRY((nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                    : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof));
-        if (panel_final) GPX_TRY((*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true));
+        if (panel_final) GPX_TRY((*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true, nullptr));
         return 0;
     }
     // outer panel boundaries (block units).  Wider early panels (12..32 blocks) were measured and are slower.
@@ -503,9 +503,27 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         const int64_t nbr = nblk - bnd(pdf);
         GPX_TRY(dalloc(&dfl_state, (chol_dataflow_state_ints(nbr) + chol_dataflow_table_ints(nbr)) / 2 + 2));
     }
+    hipEvent_t ev_df0 = nullptr, ev_df1 = nullptr;
     auto run_dataflow = [&](int64_t p_first) -> int {
+        // The caller's ride-along work for the panels BEFORE the hand-over (they are final on s now) goes to the column-solve stream,
+        // idle from here on, and runs beside the dataflow kernel (launched on fewer workgroups than the chip holds when it owns the tail
+        // only: launch_chol_dataflow); what is left -- the dataflow kernel's own panels -- follows behind both.
+        static const bool beside_env = getenv("GPX_DFLOW_BESIDE") != nullptr;   // measured: no gain at C3 (the tail kernel then has a third fewer
+                                                                                    // workers); off by default
+        const bool beside = beside_env && panel_final && p_first > 0 && s_top;
+        if (beside) {
+            GPX_HIP(hipEventCreateWithFlags(&ev_df0, hipEventDisableTiming));
+            GPX_HIP(hipEventCreateWithFlags(&ev_df1, hipEventDisableTiming));
+            GPX_HIP(hipEventRecord(ev_df0, s));
+            GPX_HIP(hipStreamWaitEvent(s_top, ev_df0, 0));
+        }
         GPX_TRY(launch_chol_dataflow(L, ld, nblk, bnd(p_first), Dinv, diagL, info_dev, reinterpret_cast<int *>(dfl_state), dfl_tab, wait_limit_ticks(), s));
-        if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true));
+        if (beside) {
+            GPX_TRY((*panel_final)(p_first - 1, 0, false, s_top));
+            GPX_HIP(hipEventRecord(ev_df1, s_top));
+            GPX_HIP(hipStreamWaitEvent(s, ev_df1, 0));
+        }
+        if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true, nullptr));
         return 0;
     };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
@@ -600,7 +618,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) {
-                if (panel_final) GPX_TRY((*panel_final)(p, 0, true));
+                if (panel_final) GPX_TRY((*panel_final)(p, 0, true, nullptr));
                 break;
             }
             if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
@@ -672,12 +690,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             // work of the caller that rides along on the main stream, behind this panel's trailing update
             static const int hook_early = [] { const char *e = getenv("GPX_HOOK_EARLY"); return e ? atoi(e) : 1; }();
             if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
-            if (panel_final && hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
+            if (panel_final && hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false, nullptr));
             if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
-            if (panel_final && !hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false));
+            if (panel_final && !hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false, nullptr));
         }
         return 0;
     };
@@ -698,6 +716,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     if (dfl_state) dfree(dfl_state);
+    if (ev_df0) (void)hipEventDestroy(ev_df0);
+    if (ev_df1) (void)hipEventDestroy(ev_df1);
     return rc;
 }
 

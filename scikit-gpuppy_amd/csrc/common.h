@@ -183,13 +183,14 @@ constexpr int64_t CHOL_PANEL_COLS = 8 * 128;   // outer panel width (CHOL_NBP ti
 int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL, int *info_dev,
                 hipStream_t s, hipStream_t s_pan, Profiler *prof, hipStream_t s_top = nullptr,
                 const std::function<int()> *after_fork = nullptr,
-                const std::function<int(int64_t, int64_t, bool)> *panel_final = nullptr);
+                const std::function<int(int64_t, int64_t, bool, hipStream_t)> *panel_final = nullptr);
 // info_dev (device ints, zero before the call): [0] potrf status (1-based failing column), [1] STALL (an in-kernel wait of the
 // look-ahead schedule expired: the factor is invalid, refit with chol_force_plain_schedule(true)); with s_pan != nullptr the schedule
 // uses 4 + nblk + 8 ints of it.
 void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top);
 void chol_concurrency_forget();
 void chol_force_plain_schedule(bool on);
+// panel_final(p, slack, last, on): (on = the stream to queue on; null = the main stream s)
 // panel_final(p, slack, last): queued on the main stream s at a point where the columns of the outer panels 0..p are final for work
 // on s; slack = outer panels whose trailing update is still to come (small = the main stream is about to idle underneath the chain:
 // the place for work that rides along), last = the factorisation has nothing more to queue

@@ -72,8 +72,48 @@ def fit_once(label):
     np.save(os.path.join(ROOT, "gpurun_out", "probe_dflow_beta_%s.npy" % label), beta)
 
 
+def bulk():
+    """the persistent loop's own tile rate (GPX_DFLOW_BULKONLY=1: panel 0's trailing tiles only, no dependencies) against the
+    hardware-dispatched trapezoid launch on the same tiles"""
+    import torch
+    from skgpuppy_amd import _gpx
+    L = _gpx.lib
+    dev = torch.device("cuda")
+    nb = int(os.environ.get("PROBE_NB", "120"))
+    n = 128 * nb
+    A = torch.rand((n, n), dtype=torch.float64, device=dev) * 1e-3
+    dinv = torch.zeros(nb * 128 * 128, dtype=torch.float64, device=dev)
+    diag = torch.zeros(n, dtype=torch.float64, device=dev)
+    info = torch.zeros(4, dtype=torch.int32, device=dev)
+    nt = nb - 16
+    tiles = nt * 8 + nt * (nt + 1) // 2
+    p = lambda t_, off=0: ctypes.c_void_p(t_.data_ptr() + 8 * off)
+    for rep in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st = L.gpx_dev_chol_dataflow(p(A), n, nb, 0, p(dinv), p(diag), ctypes.c_void_p(info.data_ptr()), None)
+        dt = time.perf_counter() - t0
+        _gpx.check(st, "dataflow bulk only")
+        print("dataflow bulk-only: %d tiles in %.3f ms = %.3f us/tile (host-timed, incl. launch + sync)" % (tiles, dt * 1e3, dt * 1e6 / tiles), flush=True)
+    cnt = torch.zeros(16, dtype=torch.int32, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for rep in range(4):
+        cnt.zero_()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # C[rows >= 16 tiles, columns >= 8 tiles] -= A[rows, 0:1024] B[...]^T : the same tiles as panel 0's trailing update
+        st = L.gpx_dev_syrk_trap(p(A, 16 * 128 * n), n, p(A, 8 * 128 * n), n, p(A, 16 * 128 * n + 8 * 128), n, nt * 128, 1024, 1024, -1.0, 1.0,
+                                 ctypes.c_void_p(cnt.data_ptr()), None)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        _gpx.check(st, "syrk_trap")
+        print("trapezoid launch:   %d tiles in %.3f ms = %.3f us/tile" % (tiles, dt * 1e3, dt * 1e6 / tiles), flush=True)
+
+
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "check"
+    if mode == "bulk":
+        return bulk()
     if mode == "check":
         check()
     elif mode == "fit":
