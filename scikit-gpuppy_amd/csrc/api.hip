@@ -230,9 +230,42 @@ void stream_release(hipStream_t s, int high_priority)
     g_stream_cache[{dev, high_priority}].push_back(s);
 }
 
+// Pinned host staging blocks (64 KB) for the few-byte arguments and results of the propagation calls: copies to / from them are truly
+// asynchronous, so a call needs ONE stream synchronisation (for its result) instead of one per stack buffer.  hipHostMalloc costs
+// ~100 us: the blocks are pooled like the device buffers.
+namespace { std::vector<double *> g_pinned_free; }
+constexpr size_t PINNED_DOUBLES = 8192;
+double *pinned_acquire()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pinned_free.empty()) { double *p = g_pinned_free.back(); g_pinned_free.pop_back(); return p; }
+    }
+    void *q = nullptr;
+    if (hipHostMalloc(&q, PINNED_DOUBLES * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (double *)q;
+}
+void pinned_release(double *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pinned_free.push_back(p);
+}
+// a few doubles from a caller's pointer (host or device: include/gpx.h) into host memory
+static int fetch_small(double *dst, const double *src, size_t n)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, src) != hipSuccess) { (void)hipGetLastError(); memcpy(dst, src, sizeof(double) * n); return 0; }   // ordinary host memory
+    if (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) { GPX_HIP(hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyDeviceToHost)); return 0; }
+    memcpy(dst, src, sizeof(double) * n);
+    return 0;
+}
+
 extern "C" int gpx_pool_trim(void)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (double *hp : g_pinned_free) (void)hipHostFree(hp);
+    g_pinned_free.clear();
     for (auto &kv : g_pool_free)
         for (void *q : kv.second) (void)hipFree(q);   // cached blocks are no longer in g_pool_live: release them to the driver
     g_pool_free.clear();
@@ -400,6 +433,7 @@ extern "C" void gpx_free(gpx_handle *h)
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
+    if (h->hstage) { pinned_release(h->hstage); h->hstage = nullptr; }
     if (h->s_pan) { (void)hipStreamSynchronize(h->s_pan); stream_release(h->s_pan, side_stream_prio()); }
     if (h->s_top) { (void)hipStreamSynchronize(h->s_top); stream_release(h->s_top, side_stream_prio()); }
     if (h->own_stream && h->stream) { (void)hipStreamSynchronize(h->stream); stream_release(h->stream, main_stream_prio()); }
@@ -915,13 +949,13 @@ static int prepare_u(gpx_handle *h, const double *u)
     const bool by_solves = !h->Kinv && h->approx_solves < approx_solve_limit();
     if (!by_solves) GPX_TRY(ensure_kinv(h));
     GPX_TRY(ensure_prop_buffers(h));
-    double uh[GPX_MAX_D];
-    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * h->d, hipMemcpyDefault));
+    if (!h->hstage && !(h->hstage = pinned_acquire())) { gpx_set_error("hipHostMalloc (staging block) failed"); return GPX_ERR_HIP; }
+    double *uh = h->hstage;              // [0, 64) u | [64, 64 + 4096) Sigma | [4160, ..) results   (pinned: the copies below are asynchronous)
+    GPX_TRY(fetch_small(uh, u, h->d));
     if (h->have_u && memcmp(uh, h->u, sizeof(double) * h->d) == 0) return 0;
     hipStream_t s = h->stream;
     h->have_u = false;
     GPX_HIP(hipMemcpyAsync(udev_ptr(h), uh, sizeof(double) * h->d, hipMemcpyHostToDevice, s));
-    GPX_HIP(hipStreamSynchronize(s));   // uh is a stack buffer
     GPX_TRY(launch_approx_build(h->x, h->n, h->npad, h->d, udev_ptr(h), h->wdev, h->v, h->vt, h->V, aux_ptr(h), cplain_ptr(h), s));
     if (by_solves) {
         // KV = V K^-1 row by row: K^-1 v = L^-T (L^-1 v) as two sweeps of the few-right-hand-side triangular solver
@@ -977,8 +1011,8 @@ extern "C" int gpx_propagate_approx(gpx_handle *h, const double *u, const double
     const int64_t np = h->npad;
     hipStream_t s = h->stream;
     GPX_TRY(prepare_u(h, u));
-    double Sh[GPX_MAX_D * GPX_MAX_D];
-    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    double *Sh = h->hstage + 64, *o = h->hstage + 64 + GPX_MAX_D * GPX_MAX_D;
+    GPX_TRY(fetch_small(Sh, Sigma, (size_t)d * d));
     GPX_HIP(hipMemcpyAsync(sigma_ptr(h), Sh, sizeof(double) * d * d, hipMemcpyHostToDevice, s));
     double *tr = aux_ptr(h);
     GPX_TRY(launch_trace(h->x, h->n, np, d, udev_ptr(h), h->wdev, sigma_ptr(h), cplain_ptr(h), tr, s));
@@ -994,9 +1028,8 @@ extern "C" int gpx_propagate_approx(gpx_handle *h, const double *u, const double
         pr.push_back({h->alpha, h->V + (int64_t)(k + 1) * np});
     }
     GPX_TRY(launch_dot_pairs(pr, np, out_ptr(h), s));
-    double o[4 + 2 * GPX_MAX_D];
     GPX_HIP(hipMemcpyAsync(o, out_ptr(h), sizeof(double) * pr.size(), hipMemcpyDeviceToHost, s));
-    GPX_HIP(hipStreamSynchronize(s));
+    GPX_HIP(hipStreamSynchronize(s));                         // the call's one synchronisation
     const double mu = o[0] + 0.5 * o[1];                      // UncertaintyPropagation.py:397-408
     const double s2 = (h->v + h->vt) - o[2];                  // :412-433  (C(u,u) = v + vt)
     double var2 = 0.0;                                        // :435-460
@@ -1138,12 +1171,13 @@ extern "C" int gpx_propagate_dvh(gpx_handle *h, const double *u, double *dvh_out
     double o[3 * GPX_MAX_D];
     GPX_HIP(hipMemcpyAsync(o, out_ptr(h), sizeof(double) * pr.size(), hipMemcpyDeviceToHost, s));
     GPX_HIP(hipStreamSynchronize(s));
+    double res[GPX_MAX_D];
     for (int k = 0; k < d; ++k) {
         const double v2 = -(o[3 * k] - o[3 * k + 1] * o[3 * k + 1]);   // UncertaintyPropagation.py:593-607
         const double v3 = -o[3 * k + 2];                               // :614-627
-        double r = v2 + v3;
-        GPX_HIP(hipMemcpy(dvh_out + k, &r, sizeof(double), hipMemcpyDefault));
+        res[k] = v2 + v3;
     }
+    GPX_HIP(hipMemcpy(dvh_out, res, sizeof(double) * d, hipMemcpyDefault));
     return 0;
 }
 
@@ -1185,8 +1219,8 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     if (want_var) GPX_TRY(ensure_kinv(h));
     GPX_TRY(ensure_prop_buffers(h));
     double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
-    GPX_HIP(hipMemcpy(uh, u, sizeof(double) * d, hipMemcpyDefault));
-    GPX_HIP(hipMemcpy(Sh, Sigma, sizeof(double) * d * d, hipMemcpyDefault));
+    GPX_TRY(fetch_small(uh, u, d));
+    GPX_TRY(fetch_small(Sh, Sigma, (size_t)d * d));
     // constants (UncertaintyPropagation.py:247-257, :292-303); Winv of the reference holds w
     std::vector<double> A((size_t)d * d), Ai((size_t)d * d), Ls((size_t)d * d), dd(d);
     double nc1 = 1.0, nc2 = 1.0;

@@ -143,6 +143,7 @@ struct gpx_handle {
     double *Z = nullptr;        // predict / inverse workspace [zrows, npad]
     int64_t zrows = 0;
     double *small = nullptr;    // small device scratch (reductions, propagate vectors)
+    double *hstage = nullptr;   // pinned host staging block of the propagation calls (api.hip, pinned_acquire)
     int64_t small_elems = 0;
 
     // propagate cache (keyed on u)
