@@ -22,7 +22,10 @@
 
 #include "leaf.h"
 
-__global__ __launch_bounds__(256) void potrf_trtri128_elim_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
+// (waves_per_eu 2..2: 185 VGPRs and NO accumulator registers -- without it the allocator books a granule of 32 AGPRs nothing uses, 224 in
+// all, and the leaf no longer fits into the 216 registers per SIMD that the CU blockers leave: it then waits ~1 ms for a CU without
+// any GEMM workgroup in every reserved panel (fit +1.5 ms; tests/test_kernel_resources.py guards the budget))
+__attribute__((amdgpu_waves_per_eu(2, 2))) __global__ __launch_bounds__(256) void potrf_trtri128_elim_kernel(double *A, long ld, double *dinv, double *diag_out, int *info,
                                                                  int col_offset, int prio)
 {
     __shared__ __attribute__((aligned(16))) double X[36 * XB];
@@ -173,8 +176,10 @@ constexpr int64_t CHOL_NBP = 8;
 int64_t chol_dataflow_state_ints(int64_t nbr);
 int64_t chol_dataflow_table_ints(int64_t nbr);
 bool chol_dataflow_supported(int64_t nbr);
+int64_t chol_dataflow_word_steps();
+int64_t chol_dataflow_word_colc(int64_t nbr, int64_t k);
 int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
-                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s);
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers = 0, int exclusive = 0);
 
 static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 
@@ -201,6 +206,11 @@ struct TopPipe {
     const int *colsig = nullptr;            // column c of the slice may be read once colsig[c] has reached colwant (the trapezoid launch's
     int colwant = 0;                        // per-column counters); null: the stream is ordered behind the update some other way
     int *stall = nullptr;                   // the factorisation's stall word (an expired wait sets it)
+    // right-looking mode (the panel's chain is a square launch of the dataflow kernel): column j is solved as soon as step j is counted in
+    // sq_state, then applied to the panel's remaining columns (one K = 128 product over all of them) once the in-square solves of column j
+    // are counted -- per step two short, wide launches instead of a product whose contraction grows with j
+    const int *sq_state = nullptr;
+    int64_t sq_rows = 0;
 };
 
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
@@ -216,6 +226,22 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
         hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + (j - B0), force ? 0x7fffffff : top->colwant,
                            force ? 1000ull : wait_limit_ticks(), top->stall);
         GPX_HIP(hipGetLastError());
+    }
+    if (top->sq_state) {
+        const int64_t B1 = B0 + top->sq_rows;
+        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_steps(), (int)(j - B0 + 1), wait_limit_ticks(), top->stall);
+        GPX_HIP(hipGetLastError());
+        GPX_TRY(launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0, top->stream, prof));
+        if (j + 1 < B1) {
+            hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_colc(top->sq_rows, j - B0),
+                               (int)(4 * (B1 - 1 - j)), wait_limit_ticks(), top->stall);
+            GPX_HIP(hipGetLastError());
+            // Z[:, j+1 .. B1) -= X_j L[j+1 .. B1, j]^T
+            static const int rl_small = [] { const char *e = getenv("GPX_SQK_RL_SMALL"); return e ? atoi(e) : 1; }();
+            GPX_TRY(launch_gemm_nt(Zt + j * TILE, ld, L + ((j + 1) * TILE) * ld + j * TILE, ld, Zt + (j + 1) * TILE, ld, M, (B1 - 1 - j) * TILE, TILE,
+                                   -1.0, 1.0, 0, top->stream, prof, 0, 0, rl_small));
+        }
+        return 0;
     }
     if (j > B0)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
@@ -517,7 +543,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_HIP(hipEventRecord(ev_df0, s));
             GPX_HIP(hipStreamWaitEvent(s_top, ev_df0, 0));
         }
-        GPX_TRY(launch_chol_dataflow(L, ld, nblk, bnd(p_first), Dinv, diagL, info_dev, reinterpret_cast<int *>(dfl_state), dfl_tab, wait_limit_ticks(), s));
+        GPX_TRY(launch_chol_dataflow(L, ld, nblk, bnd(p_first), Dinv, diagL, info_dev, reinterpret_cast<int *>(dfl_state), dfl_tab, wait_limit_ticks(), s, 0, 0));
         if (beside) {
             GPX_TRY((*panel_final)(p_first - 1, 0, false, s_top));
             GPX_HIP(hipEventRecord(ev_df1, s_top));
@@ -525,6 +551,37 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         }
         if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true, nullptr));
         return 0;
+    };
+    // (its column solves wait for the kernel's counters from another stream: needs streams that run side by side, like the trapezoid hand-off)
+    const bool concurrent_ok = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    // Square-kernel mode: the diagonal chain of a panel -- 8 x (leaf, in-square solve,
+    // rank-128 update) = 24 dependent launches -- is ONE small launch of the dataflow kernel on the panel's square (leaf + side workers,
+    // dflow.hip), and the column solves of the rows below wait for its step counter instead of for events.
+    // Used where the chain is the critical path and the chip has empty CUs for it: for the panels whose trailing update has fewer than
+    // GPX_SQK_TILES tiles left (default 1000: the last six panels at N = 16384), and -- GPX_SQK_FIRST, default on -- for the first panel
+    // (nothing but the Gram kernel's remainder runs beside it).  GPX_SQK_FROM = p forces it from panel p on (0: everywhere; -1: never).
+    static const int64_t sqk_from = [] { const char *e = getenv("GPX_SQK_FROM"); return e ? atol(e) : (int64_t)-2; }();
+    static const long sqk_tiles = [] { const char *e = getenv("GPX_SQK_TILES"); return e ? atol(e) : 1000L; }();
+    static const int sqk_first = [] { const char *e = getenv("GPX_SQK_FIRST"); return e ? atoi(e) : 1; }();
+    static const int sqk_workers = [] { const char *e = getenv("GPX_SQK_WORKERS"); return e ? atoi(e) : 32; }();
+    static const int sqk_excl = [] { const char *e = getenv("GPX_SQK_EXCL"); return e ? atoi(e) : 1; }();
+    const bool sqk_on = !g_force_plain && concurrent_ok && sqk_from != -1 && chol_dataflow_supported(CHOL_NBP);
+    constexpr int64_t SQK_STATE = 1024;                       // ints per square launch: state words + tables (chol_dataflow_state_ints(8) = 656 + 181)
+    double *sqk_buf = nullptr;
+    std::vector<std::vector<int>> sqk_tabs((size_t)P);
+    if (sqk_on) GPX_TRY(dalloc(&sqk_buf, P * SQK_STATE / 2 + 2));
+    auto sqk_state = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + pp * SQK_STATE; };
+    auto use_sqk = [&](int64_t pp) {
+        if (!sqk_on || pp < 0 || pp >= P) return false;
+        if (sqk_from >= 0) return pp >= sqk_from;
+        if (pp == 0) return sqk_first != 0;
+        const int64_t nrem = nblk - bnd(pp + 1);               // block rows below panel pp: the trailing update that runs beside its chain is panel pp - 1's
+        return nrem * (nrem + 1) / 2 + nrem * CHOL_NBP < sqk_tiles;
+    };
+    // the chain of panel pp's square [Ba, Bb) as one launch on s_pan; its column solves (rows below, stream s_top) per finished step
+    auto sqk_launch = [&](int64_t pp, int64_t Ba, int64_t Bb) -> int {
+        return launch_chol_dataflow(L, ld, Bb, Ba, Dinv, diagL, info_dev, sqk_state(pp), sqk_tabs[(size_t)pp], wait_limit_ticks(), s_pan,
+                                    std::min<int>(sqk_workers, (int)(4 * (Bb - Ba - 1) + 4)), sqk_excl);
     };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
@@ -609,9 +666,18 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         // underneath the first panel's chain
         // (the first step is queued ahead of that launch; its leaf is NOT exclusive: the Gram kernel, released on the main stream at
         // the same moment, usually wins the race for the places, and an exclusive leaf would then wait for the whole launch to drain)
+        if (use_sqk(0)) {
+            GPX_TRY(sqk_launch(0, 0, bnd(1)));
+            tops[0].sq_state = sqk_state(0);
+            tops[0].sq_rows = bnd(1);
+            if (after_fork) GPX_TRY((*after_fork)());
+            if (tops[0].stream && tops[0].r1 > tops[0].r0)
+                for (int64_t j = 0; j < bnd(1); ++j) GPX_TRY(top_column(L, ld, 0, j, Dinv, &tops[0], prof));
+        } else {
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 0));
         if (after_fork) GPX_TRY((*after_fork)());
         GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 1, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));   // nothing else fills the chip yet: every leaf finds an empty CU
+        }
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
         for (int64_t p = 0; p < P; ++p) {
@@ -644,8 +710,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
                 // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
                 // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
-                GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
-                if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
+                if (use_sqk(p + 1)) GPX_TRY(sqk_launch(p + 1, B1, B2));     // the whole chain of panel p + 1, now
+                else {
+                    GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
+                    if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
+                }
             }
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
@@ -655,7 +724,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 // boundary.  Small trailing matrices keep the two launches.
                 int merged = GPX_ERR_STATE;
                 const int64_t nrem = nblk - B2;
-                if (trap_on && nrem * (nrem + 1) / 2 >= 1024 && B2 - B1 == CHOL_NBP)
+                static const long trap_min = [] { const char *e = getenv("GPX_TRAP_MIN_TILES"); return e ? atol(e) : 1024L; }();
+                if (trap_on && nrem * (nrem + 1) / 2 >= trap_min && B2 - B1 == CHOL_NBP)
                     merged = launch_syrk_trap_signal(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, nrem * TILE, (B2 - B1) * TILE, K, -1.0, 1.0,
                                                      sig + p * CHOL_NBP, s, prof);
                 if (merged != 0 && merged != GPX_ERR_STATE) return merged;
@@ -673,7 +743,8 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                         GPX_HIP(hipEventRecord(ev_tu[p], s));
                         GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
                     }
-                    GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
+                    if (use_sqk(p + 1)) { tops[p + 1].sq_state = sqk_state(p + 1); tops[p + 1].sq_rows = B2 - B1; }   // (top_column waits for the step itself)
+                    else GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
                 if (merged != 0)
@@ -692,6 +763,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
             if (panel_final && hook_early) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false, nullptr));
             if (host_t0 >= 0) host_marks.push_back(host_now() - host_t0);
+            if (use_sqk(p + 1)) {
+                // the chain runs already (one launch); the column solves of the rows below follow its step counter
+                if (tops[p + 1].stream && tops[p + 1].r1 > tops[p + 1].r0)
+                    for (int64_t j = B1 + 1; j < B2; ++j) GPX_TRY(top_column(L, ld, B1, j, Dinv, &tops[p + 1], prof));
+            } else
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
@@ -716,6 +792,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     if (dfl_state) dfree(dfl_state);
+    if (sqk_buf) dfree(sqk_buf);
     if (ev_df0) (void)hipEventDestroy(ev_df0);
     if (ev_df1) (void)hipEventDestroy(ev_df1);
     return rc;

@@ -162,7 +162,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
 int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,
-                   hipStream_t s, Profiler *prof, int ktrim = 0, int tri = 0);
+                   hipStream_t s, Profiler *prof, int ktrim = 0, int tri = 0, int small_tiles = 0);
 // narrow update + bulk SYRK of a panel as ONE trapezoid launch that counts its finished narrow tiles in *sig_dev (gemm.hip)
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
                             double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof);

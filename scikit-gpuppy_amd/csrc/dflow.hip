@@ -31,6 +31,7 @@
 //   prog[i][s]  leading tile columns of the 32-row slab s of tile row i that are final (COL stores k + 1)
 //   diagcnt[k]  slabs of diagonal block k that have their in-panel update (DIAG adds 1; 4 = ready for the leaf)
 //   leafdone    diagonal blocks factored (k + 1)
+//   colc[k]     finished in-square COL slabs of block column k (what a right-looking update with that column outside the kernel waits for)
 //   narrow[k]   finished BULK tiles of tile column k that belong to the panel right before k's own (what column k's COL tasks read)
 //   sqrows[q] / sqbulk[q]   finished COL slabs of the last column before square q in the rows of square q / finished BULK tiles
 //               inside square q of the panel two before it: what releases the SQ tasks of square q
@@ -88,7 +89,8 @@ __device__ __forceinline__ int *st_narrow(const DflowParams &p, int k) { return 
 __device__ __forceinline__ int *st_sqrows(const DflowParams &p, int q) { return p.st + ST_DIAGCNT + 6 * p.nbr + q; }
 __device__ __forceinline__ int *st_sqbulk(const DflowParams &p, int q) { return p.st + ST_DIAGCNT + 7 * p.nbr + q; }
 __device__ __forceinline__ int *st_sqrows_a(const DflowParams &p, int q) { return p.st + ST_DIAGCNT + 8 * p.nbr + q; }
-__device__ __forceinline__ int *st_ver(const DflowParams &p, int i, int j) { return p.st + ST_DIAGCNT + 9 * p.nbr + i * p.nbr + j; }
+__device__ __forceinline__ int *st_colc(const DflowParams &p, int k) { return p.st + ST_DIAGCNT + 9 * p.nbr + k; }
+__device__ __forceinline__ int *st_ver(const DflowParams &p, int i, int j) { return p.st + ST_DIAGCNT + 10 * p.nbr + i * p.nbr + j; }
 
 // largest k in [0, n) with off[k] <= h  (off ascending, off[0] = 0, h < off[n])
 __device__ __forceinline__ int upper_step(const int *off, int n, int h)
@@ -252,6 +254,7 @@ __device__ __noinline__ bool run_col(const DflowParams &p, int i, int k, int s, 
     const unsigned long long t3 = STAMP(p);
     slab_solve(p, C, k, smem);
     publish_set(st_prog(p, i, s), k + 1);
+    if (threadIdx.x == 0 && kind == 1) (void)add_agent(st_colc(p, k), 1);   // an in-square solve: counted per block column
     // the last two columns before the next diagonal square, in a row of that square: what releases its SQ tasks (first and second part)
     if (threadIdx.x == 0 && i >= (q + 1) * NBP && i < (q + 2) * NBP) {
         if ((k + 1) % NBP == 0) (void)add_agent(st_sqrows(p, q + 1), 1);
@@ -703,7 +706,11 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 // ints of device state the kernel needs for nbr owned tiles (zeroed before the launch) / of its tables
-int64_t chol_dataflow_state_ints(int64_t nbr) { return ST_DIAGCNT + 9 * nbr + nbr * nbr; }
+int64_t chol_dataflow_state_ints(int64_t nbr) { return ST_DIAGCNT + 10 * nbr + nbr * nbr; }
+// state words a caller outside the kernel may wait for (square launches, chol.hip): the finished steps / the finished in-square solve
+// slabs of block column k (4 per block row below the diagonal block)
+int64_t chol_dataflow_word_steps() { return ST_LEAFDONE; }
+int64_t chol_dataflow_word_colc(int64_t nbr, int64_t k) { return ST_DIAGCNT + 9 * nbr + k; }
 
 bool chol_dataflow_supported(int64_t nbr)
 {
@@ -720,8 +727,11 @@ int64_t chol_dataflow_table_ints(int64_t nbr)
     return 2 * (nbr + 1) + 8 * (Q + 1) + Q + (Q + 1) + 16 * Q;
 }
 
+// workers > 0: a small launch for ONE diagonal square (nb = the square's last block + 1, c0 = its first): `workers` workgroups besides the
+// leaf, all of them on the chain queue; exclusive: every workgroup asks for 52 KB of dynamic LDS on top, so that no GEMM workgroup of
+// another launch joins it on its CU.  state_dev[0] then counts the square's finished steps (what its column solves wait for).
 int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
-                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s)
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers, int exclusive)
 {
     const int nbr = (int)(nb - c0);
     if (c0 % NBP || !chol_dataflow_supported(nbr)) { gpx_set_error("launch_chol_dataflow: unsupported shape (nb=%ld, c0=%ld)", (long)nb, (long)c0); return GPX_ERR_BAD_ARG; }
@@ -777,7 +787,7 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
     // cu_id[3:0]): 16 CUs, 32 workgroups -- what one step of the chain can use at most (28 solves + 4 diagonal slabs)
     static const int smask = [] { const char *e = getenv("GPX_DFLOW_SIDE_MASK"); return e ? (int)strtol(e, nullptr, 0) : 0x2f; }();
     static const int sval = [] { const char *e = getenv("GPX_DFLOW_SIDE_VAL"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
-    p.side_mask = smask; p.side_val = sval;
+    p.side_mask = workers > 0 ? 0 : smask; p.side_val = workers > 0 ? 0 : sval;   // (mask 0: every workgroup is a side worker)
     p.limit = limit_ticks;
     static const int nside = getenv("GPX_DFLOW_BULKONLY") ? -7 : 0;
     static const int nkeep = [] { const char *e = getenv("GPX_DFLOW_KEEP"); return e ? atoi(e) : 192; }();
@@ -801,7 +811,9 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
         GPX_HIP(hipMalloc((void **)&p.trace, sizeof(unsigned long long) * (8 + 8 * (size_t)p.trace_cap)));
         GPX_HIP(hipMemsetAsync(p.trace, 0, 64, s));
     }
-    hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)grid), dim3(256), 0, s, p);
+    static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chol_dataflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 52 * 1024); return true; }();
+    (void)attr;
+    hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)(workers > 0 ? 1 + workers : grid)), dim3(256), (workers > 0 && exclusive) ? 52 * 1024 : 0, s, p);
     GPX_HIP(hipGetLastError());
     if (trace_path) {
         GPX_HIP(hipStreamSynchronize(s));
@@ -831,7 +843,7 @@ extern "C" int gpx_dev_chol_dataflow(double *L, int64_t ld, int64_t nblk, int64_
     std::vector<int> tab;
     hipStream_t s = (hipStream_t)stream;
     static const unsigned long long lim = [] { const char *e = getenv("GPX_WAIT_LIMIT_MS"); const double ms = e ? atof(e) : 5000.0; return (unsigned long long)(ms * 1e5); }();
-    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s);
+    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s, 0, 0);
     const hipError_t e = hipStreamSynchronize(s);
     dfree(stbuf);
     GPX_TRY(rc);

@@ -185,7 +185,7 @@ int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64
 constexpr double SMALL_GRID_TILES = 192.0;
 
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M,
-                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int ktrim, int tri)
+                   int64_t N, int64_t K, double alpha, double beta, int lower_only, hipStream_t s, Profiler *prof, int ktrim, int tri, int small_tiles)
 {
     if (M % TILE || N % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) ||
         ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
@@ -244,7 +244,8 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
         const GemmBatch pa_ = {0, 0, 0, tri == GEMM_TRI_B_LOWER ? GEMM_TRI_B_LOWER_PAIRED : GEMM_TRI_B_UPPER_PAIRED};
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,
                            (long)ldb, C, (long)ldc, (int)K, alpha, beta, (int)(N / TILE), 0, 0, pa_, nb_, nb_);
-    } else if (tiles >= SMALL_GRID_TILES) GPX_LAUNCH(4, 4);
+    } else if (tiles >= SMALL_GRID_TILES && !small_tiles) GPX_LAUNCH(4, 4);   // small_tiles: a short product (K = 128) issued next to a
+                                                                              // saturating launch -- 64 x 64 tiles find places sooner
     else if (lower_only && tiles <= 40.0 && K >= 512 && K <= 2048 && !ktrim) GPX_LAUNCH(1, 1);   // a 1024 x 1024 square with a long contraction (the update that
                                                                                      // gates the factorisation's next chain): 32 x 32 tiles put two
                                                                                      // workgroups on every CU, 64 x 64 tiles one on half of them

@@ -1310,7 +1310,9 @@ def test_fallback_schedules_agree_and_do_not_stall(tmp_path):
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     variants = {"default": {}, "one_priority_class": {"GPX_SIDE_PRIO": "0", "GPX_BLK_PRIO": "0"}, "serialised": {"GPX_CONCURRENT_STREAMS": "0"},
-                "alpha_after_the_factorisation": {"GPX_FIT_RIDE": "0"}}
+                "alpha_after_the_factorisation": {"GPX_FIT_RIDE": "0"},
+                # the diagonal chain as one square launch of the dataflow kernel per panel: nowhere / everywhere (default: first panel + tail)
+                "launch_per_step_chains": {"GPX_SQK_FROM": "-1"}, "square_kernel_everywhere": {"GPX_SQK_FROM": "0", "GPX_RESERVE_CUS": "0"}}
     code = _SCHEDULE_WORKER % {"root": ROOT, "pkg": os.path.join(ROOT, "scikit-gpuppy_amd")}
     betas, secs = {}, {}
     for name, extra in variants.items():

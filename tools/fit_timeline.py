@@ -18,6 +18,8 @@ def load(path):
 def short(n):
     if "potrf" in n:
         return "LEAF"
+    if "chol_dataflow" in n:
+        return "SQK"
     if "persistent" in n:
         return "G44P"
     if "trap_signal" in n:
@@ -58,6 +60,9 @@ def main():
             p // 8, (grp[0][1] - t0) / 1e3, (grp[-1][2] - t0) / 1e3, (grp[-1][2] - grp[0][1]) / 1e3,
             " ".join("%4.0f" % ((g[2] - g[1]) / 1e3) for g in grp),
             ("bulk %8.1f -> %8.1f (%6.1f us, %d wgs)" % ((b[1] - t0) / 1e3, (b[2] - t0) / 1e3, (b[2] - b[1]) / 1e3, b[4])) if b else ""))
+    for r in win:
+        if short(r[0]) == "SQK":
+            print("  square kernel %8.1f -> %8.1f (%7.1f us, %d wgs)" % ((r[1] - t0) / 1e3, (r[2] - t0) / 1e3, (r[2] - r[1]) / 1e3, r[4]))
     tail = [r for r in win if r[1] > leaves[-1][2]]
     print("after the last leaf: %.1f us, %d launches" % ((win[-1][2] - leaves[-1][2]) / 1e3, len(tail)))
 

@@ -120,7 +120,11 @@ def main():
         fit_once(sys.argv[2])
     else:
         for frm in sys.argv[2:] or ["off", "-6", "-8", "-10", "0"]:
-            env = dict(os.environ, GPX_DFLOW_FROM=frm)
+            if "=" in frm:      # a variant given as environment assignments: A=1,B=2 (the dataflow hand-over stays off)
+                env = dict(os.environ, GPX_DFLOW_FROM="off")
+                env.update(dict(kv.split("=", 1) for kv in frm.split(",")))
+            else:
+                env = dict(os.environ, GPX_DFLOW_FROM=frm)
             subprocess.run([sys.executable, os.path.abspath(__file__), "fit", frm], env=env, timeout=300)
         base = np.load(os.path.join(ROOT, "gpurun_out", "probe_dflow_beta_off.npy"))
         for frm in sys.argv[2:] or ["-6", "-8", "-10", "0"]:
