@@ -59,3 +59,14 @@ def test_register_budget_of_the_cu_reservation(tmp_path):
     for frag in ("gemm_nt_f64_kernelILi2ELi2E", "gemm_nt_f64_kernelILi1ELi4E", "gemm_nt_f64_kernelILi1ELi1E"):
         for k, u in pick(gemm, frag).items():
             assert 2 * alloc(u) <= FREE, (k, u)
+
+
+@pytest.mark.timeout(1800)
+def test_dataflow_kernel_keeps_two_workgroups_per_cu(tmp_path):
+    """The persistent dataflow kernel (dflow.hip) hides a workgroup's between-task work behind its CU mate's products: it needs TWO
+    workgroups per CU -- at most 256 registers per wave (arch + accumulation: a granule of 32 AGPRs that nothing uses once pushed it to
+    288 and to one workgroup per CU, silently) and at most 80 KB of LDS per workgroup."""
+    usage = resource_usage("dflow.hip", tmp_path)
+    for k, u in pick(usage, "chol_dataflow_kernel").items():
+        assert alloc(u) <= 256, (k, u)
+        assert u["LDS"] <= 80 * 1024, (k, u)
