@@ -862,7 +862,10 @@ static int ensure_kinv(gpx_handle *h)
     GPX_TRY(dalloc(&K, h->npad * h->npad));
     int rc = 0;
     // Z = L^-T (upper triangular, structured recursion) ; Kinv = Z Z^T = L^-T L^-1 (lower strips, then mirrored)
-    if ((rc = build_kinv_from_factor(h->L, h->npad, h->nblk, h->Dinv, h->Z, K, s, &h->prof))) {
+    // (GPX_KINV_LEAF128=1: the 128-column leaves of chol.hip, which handles without a prepared solver use anyway)
+    static const int leaf128 = [] { const char *e = getenv("GPX_KINV_LEAF128"); return e ? atoi(e) : 0; }();
+    if ((rc = (h->tri.ready() && !leaf128) ? build_kinv_from_solver(&h->tri, h->Z, K, s, &h->prof)
+                                           : build_kinv_from_factor(h->L, h->npad, h->nblk, h->Dinv, h->Z, K, s, &h->prof))) {
         dfree(K);
         return rc;
     }

@@ -179,7 +179,9 @@ bool chol_dataflow_supported(int64_t nbr);
 int64_t chol_dataflow_word_steps();
 int64_t chol_dataflow_word_colc(int64_t nbr, int64_t k);
 int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
-                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers = 0, int exclusive = 0);
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers = 0, int exclusive = 0,
+                         const int *tab_ready = nullptr);
+int chol_dataflow_upload_tables(int nbr, int *tab_dev, std::vector<int> &host_tab, hipStream_t s);
 
 static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 
@@ -566,11 +568,16 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     static const int sqk_workers = [] { const char *e = getenv("GPX_SQK_WORKERS"); return e ? atoi(e) : 32; }();
     static const int sqk_excl = [] { const char *e = getenv("GPX_SQK_EXCL"); return e ? atoi(e) : 1; }();
     const bool sqk_on = !g_force_plain && concurrent_ok && sqk_from != -1 && chol_dataflow_supported(CHOL_NBP);
-    constexpr int64_t SQK_STATE = 1024;                       // ints per square launch: state words + tables (chol_dataflow_state_ints(8) = 656 + 181)
+    // State words: 1024 ints per panel (chol_dataflow_state_ints(8) = 656), zeroed on the MAIN stream in front of the factorisation's first
+    // event -- the column solves on s_top poll them, and a recycled buffer holds the previous fit's finished counters; the task tables of
+    // a full square and of a shorter last one are uploaded once, behind the states.
+    constexpr int64_t SQK_STATE = 1024, SQK_TAB = 256;
     double *sqk_buf = nullptr;
     std::vector<std::vector<int>> sqk_tabs((size_t)P);
-    if (sqk_on) GPX_TRY(dalloc(&sqk_buf, P * SQK_STATE / 2 + 2));
+    std::vector<int> sqk_tab_full, sqk_tab_last;
+    if (sqk_on) GPX_TRY(dalloc(&sqk_buf, (P * SQK_STATE + 2 * SQK_TAB) / 2 + 2));
     auto sqk_state = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + pp * SQK_STATE; };
+    auto sqk_tab = [&](int64_t rows) { return reinterpret_cast<int *>(sqk_buf) + P * SQK_STATE + (rows == CHOL_NBP ? 0 : SQK_TAB); };
     auto use_sqk = [&](int64_t pp) {
         if (!sqk_on || pp < 0 || pp >= P) return false;
         if (sqk_from >= 0) return pp >= sqk_from;
@@ -581,7 +588,19 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // the chain of panel pp's square [Ba, Bb) as one launch on s_pan; its column solves (rows below, stream s_top) per finished step
     auto sqk_launch = [&](int64_t pp, int64_t Ba, int64_t Bb) -> int {
         return launch_chol_dataflow(L, ld, Bb, Ba, Dinv, diagL, info_dev, sqk_state(pp), sqk_tabs[(size_t)pp], wait_limit_ticks(), s_pan,
-                                    std::min<int>(sqk_workers, (int)(4 * (Bb - Ba - 1) + 4)), sqk_excl);
+                                    std::min<int>(sqk_workers, (int)(4 * (Bb - Ba - 1) + 4)), sqk_excl, sqk_tab(Bb - Ba));
+    };
+    auto sqk_prepare = [&]() -> int {   // on s, in front of ev0
+        if (!sqk_on) return 0;
+        bool any = false, shorter = false;
+        for (int64_t pp = 0; pp < P; ++pp)
+            if (use_sqk(pp)) { any = true; if (bnd(pp + 1) - bnd(pp) != CHOL_NBP) shorter = true; }
+        if (!any) return 0;
+        if (chol_dataflow_table_ints(CHOL_NBP) > SQK_TAB) { gpx_set_error("chol_factor: square-kernel table larger than its slot"); return GPX_ERR_STATE; }
+        GPX_HIP(hipMemsetAsync(sqk_buf, 0, sizeof(int) * (size_t)(P * SQK_STATE), s));
+        GPX_TRY(chol_dataflow_upload_tables(CHOL_NBP, sqk_tab(CHOL_NBP), sqk_tab_full, s));
+        if (shorter) GPX_TRY(chol_dataflow_upload_tables((int)(nblk - bnd(P - 1)), sqk_tab(0), sqk_tab_last, s));
+        return 0;
     };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
@@ -651,6 +670,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             return run_dataflow(0);
         }
         if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP), s));
+        GPX_TRY(sqk_prepare());
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
@@ -729,9 +749,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     merged = launch_syrk_trap_signal(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, nrem * TILE, (B2 - B1) * TILE, K, -1.0, 1.0,
                                                      sig + p * CHOL_NBP, s, prof);
                 if (merged != 0 && merged != GPX_ERR_STATE) return merged;
+                // (beside a square kernel the next panel's column solves wait for this launch and the chip is nearly empty: 64 x 64 tiles
+                // finish in a third of a 128 x 128 tile's time -- GPX_SQK_NARROW_SMALL)
+                static const int narrow_small = [] { const char *e = getenv("GPX_SQK_NARROW_SMALL"); return e ? atoi(e) : 1; }();
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
-                                           K, -1.0, 1.0, 0, s, prof));
+                                           K, -1.0, 1.0, 0, s, prof, 0, 0, (narrow_small && use_sqk(p + 1) && p + 1 > 0) ? 1 : 0));
                 if (piped(p + 1) && !handover) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     if (merged == 0) {
                         // every column solve waits for its own column's narrow tiles (top_column).  Handing the count over as an event

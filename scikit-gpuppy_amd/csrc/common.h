@@ -209,6 +209,9 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
                           hipStream_t s, Profiler *prof);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
+// the same from a prepared few-vector solver: its inverted 1024 x 1024 diagonal squares are the leaves (tsolve.hip); Kinv doubles as scratch
+int build_kinv_from_solver(const TriSolver *ts, double *Z, double *Kinv, hipStream_t s, Profiler *prof);
+int build_linv_t_squares(const TriSolver *ts, double *A, double *Z, hipStream_t s, Profiler *prof);
 // Z [npad, npad] <- L^-T (upper triangular, row-major) from the factor and its inverted diagonal blocks
 int build_linv_t(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, hipStream_t s, Profiler *prof);
 int launch_logdet(const double *diagL, int64_t n, double *out_dev, hipStream_t s);

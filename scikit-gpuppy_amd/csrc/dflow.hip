@@ -730,13 +730,10 @@ int64_t chol_dataflow_table_ints(int64_t nbr)
 // workers > 0: a small launch for ONE diagonal square (nb = the square's last block + 1, c0 = its first): `workers` workgroups besides the
 // leaf, all of them on the chain queue; exclusive: every workgroup asks for 52 KB of dynamic LDS on top, so that no GEMM workgroup of
 // another launch joins it on its CU.  state_dev[0] then counts the square's finished steps (what its column solves wait for).
-int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
-                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers, int exclusive)
+// the task tables of a factorisation of nbr block rows (what the kernel keeps in LDS)
+static void dataflow_tables(int nbr, std::vector<int> &host_tab)
 {
-    const int nbr = (int)(nb - c0);
-    if (c0 % NBP || !chol_dataflow_supported(nbr)) { gpx_set_error("launch_chol_dataflow: unsupported shape (nb=%ld, c0=%ld)", (long)nb, (long)c0); return GPX_ERR_BAD_ARG; }
     const int Q = (nbr + NBP - 1) / NBP;
-    // ---- tables ----
     host_tab.assign((size_t)chol_dataflow_table_ints(nbr), 0);
     int *chain = host_tab.data(), *col = chain + (nbr + 1), *bulk = col + (nbr + 1), *mode = bulk + 8 * (Q + 1), *sq = mode + Q, *geo = sq + (Q + 1);
     for (int k = 0; k < nbr; ++k) {
@@ -775,10 +772,36 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
             }
         }
     }
-    const int64_t nstate = chol_dataflow_state_ints(nbr);
-    int *tab_dev = state_dev + nstate;
-    GPX_HIP(hipMemsetAsync(state_dev, 0, sizeof(int) * (size_t)nstate, s));
+}
+
+// tables of an nbr-row factorisation -> tab_dev (chol_dataflow_table_ints(nbr) ints) on stream s: for callers that launch several squares
+// of one shape and zero their state words themselves (launch_chol_dataflow's tab_ready)
+int chol_dataflow_upload_tables(int nbr, int *tab_dev, std::vector<int> &host_tab, hipStream_t s)
+{
+    if (!chol_dataflow_supported(nbr)) { gpx_set_error("chol_dataflow_upload_tables: unsupported shape (%d block rows)", nbr); return GPX_ERR_BAD_ARG; }
+    dataflow_tables(nbr, host_tab);
     GPX_HIP(hipMemcpyAsync(tab_dev, host_tab.data(), sizeof(int) * host_tab.size(), hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// tab_ready: the caller has zeroed the state words and uploaded the tables (chol_dataflow_upload_tables) in front of everything that
+// may look at the state -- a launch that zeroes its own state on ITS stream is only safe when nothing on another stream polls that state
+// before the launch (the square-kernel mode's column solves do: a recycled buffer would show them the previous fit's finished counters)
+int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers, int exclusive, const int *tab_ready)
+{
+    const int nbr = (int)(nb - c0);
+    if (c0 % NBP || !chol_dataflow_supported(nbr)) { gpx_set_error("launch_chol_dataflow: unsupported shape (nb=%ld, c0=%ld)", (long)nb, (long)c0); return GPX_ERR_BAD_ARG; }
+    const int Q = (nbr + NBP - 1) / NBP;
+    dataflow_tables(nbr, host_tab);
+    const int *chain = host_tab.data(), *col = chain + (nbr + 1), *sq = col + (nbr + 1) + 8 * (Q + 1) + Q;
+    const int64_t nstate = chol_dataflow_state_ints(nbr);
+    const int *tab_dev = tab_ready;
+    if (!tab_ready) {
+        GPX_HIP(hipMemsetAsync(state_dev, 0, sizeof(int) * (size_t)nstate, s));
+        GPX_HIP(hipMemcpyAsync(state_dev + nstate, host_tab.data(), sizeof(int) * host_tab.size(), hipMemcpyHostToDevice, s));
+        tab_dev = state_dev + nstate;
+    }
     DflowParams p;
     p.L = L; p.ld = (long)ld; p.Dinv = Dinv; p.diag = diag; p.info = info_dev; p.st = state_dev; p.tab = tab_dev; p.ntab = (int)host_tab.size();
     p.nb = (int)nb; p.c0 = (int)c0; p.nbr = nbr; p.Q = Q;
@@ -843,7 +866,7 @@ extern "C" int gpx_dev_chol_dataflow(double *L, int64_t ld, int64_t nblk, int64_
     std::vector<int> tab;
     hipStream_t s = (hipStream_t)stream;
     static const unsigned long long lim = [] { const char *e = getenv("GPX_WAIT_LIMIT_MS"); const double ms = e ? atof(e) : 5000.0; return (unsigned long long)(ms * 1e5); }();
-    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s, 0, 0);
+    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s, 0, 0, nullptr);
     const hipError_t e = hipStreamSynchronize(s);
     dfree(stbuf);
     GPX_TRY(rc);

@@ -426,3 +426,66 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
     GPX_TRY(launch_gemm_nt(Zs + c0, ldz, ts->L + cm * ts->ld + c0, ts->ld, Z + cm, ldz, rows, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
     return trsm_right_lt_squares(Z, Zs, ldz, rows, ts, pm, p1, s, prof);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// L^-T (upper triangular, for K^-1 = L^-T L^-1: skgpuppy/Covariance.py:167-187) with the inverted diagonal squares as leaves.
+// The 128-leaf recursion (chol.hip, trtri_upper_rec) spends 8 of its 27 ms at C3 below the 1024-column level: per square 24
+// one-tile-column leaf launches, 7 short-K updates and an identity fill of the whole matrix.  Here the diagonal square of
+// column slab p IS inv(L_pp)^T (copied, zero below its diagonal), the rows above it are ONE product of the slab's accumulated
+// right-hand side with inv(L_pp)^T (zero triangle skipped), and the updates between slabs keep the recursion's shape:
+//     Zs[0:k0, slab p] = A[0:k0, slab p] inv(L_pp)^T ,   A[0:cm, cm:c1) -= Zs[0:cm, c0:cm) L[cm:c1, c0:cm)^T
+// A is scratch (the K^-1 buffer itself, overwritten by Z Z^T afterwards); a block of A is WRITTEN (beta = 0) by the first update
+// that reaches it -- the rows [c0, cm) of the update of range (c0, c1) -- so no fill is needed, and that part of the update
+// contracts over k >= its own row only (Zs is upper triangular there).  Blocks of Zs below the diagonal squares are never
+// written and never read (the Z Z^T launch contracts over k >= the row tile's first row).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ts_copy_upper_kernel(const double *__restrict__ Pz, double *__restrict__ Z, long ldz, int K)
+{
+    const int r = blockIdx.x;                                  // row of the square
+    const double *src = Pz + (long)r * PB;
+    double *dst = Z + (long)r * ldz;
+    for (int c = 2 * threadIdx.x; c < K; c += 512) {
+        v2d v = *reinterpret_cast<const v2d *>(src + c);
+        if (c < r) v.x = 0.0;
+        if (c + 1 < r) v.y = 0.0;
+        *reinterpret_cast<v2d *>(dst + c) = v;
+    }
+}
+
+static int trtri_squares_rec(double *A, double *Zs, int64_t ldz, const TriSolver *ts, int64_t p0, int64_t p1, hipStream_t s, Profiler *prof)
+{
+    const int64_t np = p1 - p0;
+    if (np <= 0) return 0;
+    if (np == 1) {
+        const int64_t k0 = p0 * PB, K = std::min<int64_t>(PB, ts->npad - k0);
+        hipLaunchKernelGGL(ts_copy_upper_kernel, dim3((unsigned)K), dim3(256), 0, s, (const double *)(ts->Pz + p0 * (int64_t)PB * PB), Zs + k0 * ldz + k0, (long)ldz, (int)K);
+        GPX_HIP(hipGetLastError());
+        if (k0 == 0) return 0;
+        return launch_gemm_nt(A + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, k0, K, K, 1.0, 0.0, 0, s, prof, 0, GEMM_TRI_B_LOWER);
+    }
+    int64_t h = 1;
+    while (h * 2 < np) h *= 2;
+    const int64_t pm = p0 + h;
+    GPX_TRY(trtri_squares_rec(A, Zs, ldz, ts, p0, pm, s, prof));
+    const int64_t c0 = p0 * PB, cm = pm * PB, c1 = std::min<int64_t>(p1 * PB, ts->npad);
+    const double *Lb = ts->L + cm * ts->ld + c0;
+    if (c0 > 0) GPX_TRY(launch_gemm_nt(Zs + c0, ldz, Lb, ts->ld, A + cm, ldz, c0, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
+    GPX_TRY(launch_gemm_nt(Zs + c0 * ldz + c0, ldz, Lb, ts->ld, A + c0 * ldz + cm, ldz, cm - c0, c1 - cm, cm - c0, -1.0, 0.0, 0, s, prof, 1));
+    return trtri_squares_rec(A, Zs, ldz, ts, pm, p1, s, prof);
+}
+
+// Z [npad, npad] <- L^-T for the factor the solver is attached to; A: scratch of the same shape (contents undefined afterwards)
+int build_linv_t_squares(const TriSolver *ts, double *A, double *Z, hipStream_t s, Profiler *prof)
+{
+    if (!ts || !ts->ready()) { gpx_set_error("build_linv_t_squares: solver not prepared"); return GPX_ERR_STATE; }
+    return trtri_squares_rec(A, Z, ts->npad, ts, 0, ts->P, s, prof);
+}
+
+// Kinv = L^-T L^-1 with Kinv itself as the recursion's scratch
+int build_kinv_from_solver(const TriSolver *ts, double *Z, double *Kinv, hipStream_t s, Profiler *prof)
+{
+    GPX_TRY(build_linv_t_squares(ts, Kinv, Z, s, prof));
+    const int64_t npad = ts->npad;
+    GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 1));
+    return launch_symmetrize_lower(Kinv, npad, npad, s);
+}

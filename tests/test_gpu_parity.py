@@ -968,7 +968,7 @@ def test_approx_propagation_solve_path_equals_kinv_path():
     assert a0[1] == pytest.approx(float(g["approx_u0_S0"][1]), abs=1e-8 * v)
 
 
-@pytest.mark.parametrize("N,d,nrhs", [(100, 2, 1), (1024, 3, 9), (1100, 4, 17), (2500, 5, 40), (3072, 2, 16)])
+@pytest.mark.parametrize("N,d,nrhs", [(100, 2, 1), (1024, 3, 9), (1100, 4, 17), (2500, 5, 40), (3072, 2, 16), (4224, 3, 20)])
 def test_solve_few_right_hand_sides_against_oracle(N, d, nrhs):
     """gpx_solve = the fat-step triangular solver behind alpha and the post-fit propagation: one, exactly eight, nine and
     more 128-blocks (whole and partial 1024-row steps), one and two groups of 16 right-hand sides, more than 32."""
@@ -989,6 +989,25 @@ def test_solve_few_right_hand_sides_against_oracle(N, d, nrhs):
     np.testing.assert_allclose(kb, ko, rtol=0, atol=1e-7 * np.abs(ko).max())
     # residual of the solve itself: K (K^-1 b) = b
     np.testing.assert_allclose(K.dot(kb.T).T, B, rtol=0, atol=1e-8 * np.abs(kb).max())
+
+
+@pytest.mark.parametrize("N", [1100, 2500, 4224, 5000])
+def test_kinv_with_inverted_squares_as_leaves(N):
+    """K^-1 = L^-T L^-1 through the recursion whose leaves are the few-vector solver's inverted 1024 x 1024 squares (tsolve.hip,
+    build_kinv_from_solver): two to five column slabs, whole and partial last squares, against the oracle's inverse entry by entry
+    and as K K^-1 = I."""
+    d = 3
+    rng = np.random.RandomState(11 + N)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    Kinv = gp.Kinv
+    K = orc.gram(x, theta)
+    ref = np.linalg.inv(K)
+    np.testing.assert_allclose(Kinv, ref, rtol=0, atol=1e-7 * np.abs(ref).max())
+    np.testing.assert_allclose(Kinv, Kinv.T, rtol=0, atol=0)
+    np.testing.assert_allclose(K.dot(Kinv), np.eye(N), rtol=0, atol=1e-7)
 
 
 @pytest.mark.parametrize("N,d,k", [(64, 2, 3), (1300, 3, 33)])
