@@ -23,25 +23,22 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const double *__restric
     out[e] = (i < n) ? x[e] * sw[k] : 0.0;
 }
 
+// The rows' inputs are WAVE-UNIFORM (a wave owns 16 rows, a lane two columns): they are read straight from global memory through
+// the scalar cache into SGPRs -- as LDS broadcasts (rounds 1-3) the 16 reads per k and wave made the LDS pipe, not the fp64 VALU,
+// the bound of the difference loop (4 waves x 16 x 4 cycles against 32 x 4 VALU cycles per SIMD and k): d = 16 ran at 3.1 TB/s.
 __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi, long n1,
                                                   const double *__restrict__ xj, long n2, int d, double v,
                                                   double add_diag, int lower_only, int pad_mode,
                                                   double *__restrict__ out, long ld)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *a_s = smem;               // [64][d]   rows of xi (scaled), read as wave-uniform broadcasts
-    double *b_s = smem + GR_ROWS * d; // [d][128]  columns of xj (scaled), k-major so a lane reads 2 adjacent columns
+    double *b_s = smem;               // [d][128]  columns of xj (scaled), k-major so a lane reads 2 adjacent columns
 
     const long row0 = (long)blockIdx.y * GR_ROWS;
     const long col0 = (long)blockIdx.x * GR_COLS;
     if (lower_only && col0 > row0 + (GR_ROWS - 1)) return;   // tile entirely above the diagonal
 
     const int t = threadIdx.x;
-    for (int e = t; e < GR_ROWS * d; e += 256) {
-        int r = e / d;
-        long gr = row0 + r;
-        a_s[e] = (gr < n1) ? xi[gr * d + (e - r * d)] : 0.0;
-    }
     for (int e = t; e < GR_COLS * d; e += 256) {
         int c = e & (GR_COLS - 1), k = e >> 7;
         long gc = col0 + c;
@@ -49,17 +46,36 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
     }
     __syncthreads();
 
-    const int wave = t >> 6, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
     double acc0[16], acc1[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
 
-    const double *arow = a_s + (wave * 16) * d;
-    for (int k = 0; k < d; ++k) {
+    // rows past n1 (padding) read the last real row: their outputs are overwritten below
+    const long rbase = row0 + wave * 16;
+    const double *arow[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) arow[r] = xi + (rbase + r < n1 ? rbase + r : n1 - 1) * d;
+    int k = 0;
+    for (; k + 2 <= d; k += 2) {
+        const v2d b0 = *reinterpret_cast<const v2d *>(&b_s[k * GR_COLS + 2 * lane]);
+        const v2d b1 = *reinterpret_cast<const v2d *>(&b_s[(k + 1) * GR_COLS + 2 * lane]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double a0 = arow[r][k], a1 = arow[r][k + 1];
+            double e0 = a0 - b0.x, e1 = a0 - b0.y;
+            acc0[r] = fma(e0, e0, acc0[r]);
+            acc1[r] = fma(e1, e1, acc1[r]);
+            e0 = a1 - b1.x; e1 = a1 - b1.y;
+            acc0[r] = fma(e0, e0, acc0[r]);
+            acc1[r] = fma(e1, e1, acc1[r]);
+        }
+    }
+    if (k < d) {
         const v2d b = *reinterpret_cast<const v2d *>(&b_s[k * GR_COLS + 2 * lane]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const double a = arow[r * d + k];
+            const double a = arow[r][k];
             const double d0 = a - b.x, d1 = a - b.y;
             acc0[r] = fma(d0, d0, acc0[r]);
             acc1[r] = fma(d1, d1, acc1[r]);
@@ -67,6 +83,17 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
     }
 
     const long gc = col0 + 2 * lane;
+    // a tile that touches neither the diagonal nor the padding (all but a few per mille of them) skips the per-entry tests
+    if (row0 + GR_ROWS <= n1 && col0 + GR_COLS <= n2 && (col0 >= row0 + GR_ROWS || col0 + GR_COLS <= row0)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            v2d o;
+            o.x = v * exp_nonpos(-0.5 * acc0[r]);
+            o.y = v * exp_nonpos(-0.5 * acc1[r]);
+            *reinterpret_cast<v2d *>(&out[(rbase + r) * ld + gc]) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long gr = row0 + wave * 16 + r;
@@ -107,7 +134,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
     }
     if (rows_pad == 0 || cols_pad == 0) return 0;
     dim3 grid((unsigned)(cols_pad / GR_COLS), (unsigned)(rows_pad / GR_ROWS));
-    size_t lds = (size_t)(GR_ROWS + GR_COLS) * d * sizeof(double);
+    size_t lds = (size_t)GR_COLS * d * sizeof(double);
     double stored = lower_only ? 0.5 * (double)rows_pad * (double)cols_pad : (double)rows_pad * (double)cols_pad;
     ProfScope ps(prof, s, GPX_K_GRAM, 8.0 * stored);
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, s, xi_w, (long)n1, xj_w, (long)n2, d, v, add_diag,
