@@ -180,8 +180,8 @@ int64_t chol_dataflow_word_steps();
 int64_t chol_dataflow_word_colc(int64_t nbr, int64_t k);
 int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
                          std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers = 0, int exclusive = 0,
-                         const int *tab_ready = nullptr);
-int chol_dataflow_upload_tables(int nbr, int *tab_dev, std::vector<int> &host_tab, hipStream_t s);
+                         const int *tab_ready = nullptr, int first_rows = 0, int extra = 0, const int *gate = nullptr);
+int chol_dataflow_fill_tables(int nbr, int first_rows, int *dst, int cap);
 
 static_assert(CHOL_NBP * TILE == CHOL_PANEL_COLS, "common.h: CHOL_PANEL_COLS");
 
@@ -212,7 +212,8 @@ struct TopPipe {
     // sq_state, then applied to the panel's remaining columns (one K = 128 product over all of them) once the in-square solves of column j
     // are counted -- per step two short, wide launches instead of a product whose contraction grows with j
     const int *sq_state = nullptr;
-    int64_t sq_rows = 0;
+    int64_t sq_rows = 0;                    // block rows of the square
+    int64_t sq_nbr = 0;                     // block rows the square launch owns (its state layout: the square's + the rows it solves below)
 };
 
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
@@ -235,7 +236,7 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
         GPX_HIP(hipGetLastError());
         GPX_TRY(launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0, top->stream, prof));
         if (j + 1 < B1) {
-            hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_colc(top->sq_rows, j - B0),
+            hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_colc(top->sq_nbr, j - B0),
                                (int)(4 * (B1 - 1 - j)), wait_limit_ticks(), top->stall);
             GPX_HIP(hipGetLastError());
             // Z[:, j+1 .. B1) -= X_j L[j+1 .. B1, j]^T
@@ -571,13 +572,22 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // State words: 1024 ints per panel (chol_dataflow_state_ints(8) = 656), zeroed on the MAIN stream in front of the factorisation's first
     // event -- the column solves on s_top poll them, and a recycled buffer holds the previous fit's finished counters; the task tables of
     // a full square and of a shorter last one are uploaded once, behind the states.
-    constexpr int64_t SQK_STATE = 1024, SQK_TAB = 256;
+    // GPX_SQK_NEXT (default 1): the square launch also solves the NEXT diagonal square's rows for its columns (COL tasks of GPX_SQK_EXTRA
+    // more workgroups, in step with the chain), so that the update of the next square -- what the next chain waits for -- follows the
+    // launch at once instead of waiting for the column solves of ALL rows below on the third stream; those keep the rows further down,
+    // which only the trailing update needs.  The rows reach the launch through another stream's update: gate word per panel, set behind it.
+    constexpr int64_t SQK_STATE = 1024, SQK_TAB = 256, SQK_GATE = 1008;
+    static const int sqk_next = [] { const char *e = getenv("GPX_SQK_NEXT"); return e ? atoi(e) : 1; }();
+    static const int sqk_extra = [] { const char *e = getenv("GPX_SQK_EXTRA"); return e ? atoi(e) : 32; }();
     double *sqk_buf = nullptr;
     std::vector<std::vector<int>> sqk_tabs((size_t)P);
-    std::vector<int> sqk_tab_full, sqk_tab_last;
-    if (sqk_on) GPX_TRY(dalloc(&sqk_buf, (P * SQK_STATE + 2 * SQK_TAB) / 2 + 2));
+    std::vector<int> sqk_tab_host;
+    if (sqk_on) GPX_TRY(dalloc(&sqk_buf, (P * SQK_STATE + P * SQK_TAB) / 2 + 2));
     auto sqk_state = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + pp * SQK_STATE; };
-    auto sqk_tab = [&](int64_t rows) { return reinterpret_cast<int *>(sqk_buf) + P * SQK_STATE + (rows == CHOL_NBP ? 0 : SQK_TAB); };
+    auto sqk_tab = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + P * SQK_STATE + pp * SQK_TAB; };
+    auto sqk_gate = [&](int64_t pp) { return sqk_state(pp) + SQK_GATE; };
+    // block rows below panel pp's square that its square launch solves as well (the next square's)
+    auto sqk_below = [&](int64_t pp) -> int64_t { return (sqk_next && sqk_extra > 0 && s_top) ? bnd(pp + 2) - bnd(pp + 1) : 0; };
     auto use_sqk = [&](int64_t pp) {
         if (!sqk_on || pp < 0 || pp >= P) return false;
         if (sqk_from >= 0) return pp >= sqk_from;
@@ -587,20 +597,32 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     };
     // the chain of panel pp's square [Ba, Bb) as one launch on s_pan; its column solves (rows below, stream s_top) per finished step
     auto sqk_launch = [&](int64_t pp, int64_t Ba, int64_t Bb) -> int {
-        return launch_chol_dataflow(L, ld, Bb, Ba, Dinv, diagL, info_dev, sqk_state(pp), sqk_tabs[(size_t)pp], wait_limit_ticks(), s_pan,
-                                    std::min<int>(sqk_workers, (int)(4 * (Bb - Ba - 1) + 4)), sqk_excl, sqk_tab(Bb - Ba));
+        const int64_t below = sqk_below(pp);
+        return launch_chol_dataflow(L, ld, Bb + below, Ba, Dinv, diagL, info_dev, sqk_state(pp), sqk_tabs[(size_t)pp], wait_limit_ticks(), s_pan,
+                                    std::min<int>(sqk_workers, (int)(4 * (Bb - Ba - 1) + 4)), sqk_excl, sqk_tab(pp), (int)(Bb - Ba),
+                                    below > 0 ? sqk_extra : 0, sqk_gate(pp));
     };
-    auto sqk_prepare = [&]() -> int {   // on s, in front of ev0
+    auto sqk_prepare = [&]() -> int {   // on s, in front of ev0: states zeroed, every square launch's tables uploaded (one copy)
         if (!sqk_on) return 0;
-        bool any = false, shorter = false;
+        bool any = false;
+        sqk_tab_host.assign((size_t)(P * SQK_TAB), 0);
         for (int64_t pp = 0; pp < P; ++pp)
-            if (use_sqk(pp)) { any = true; if (bnd(pp + 1) - bnd(pp) != CHOL_NBP) shorter = true; }
+            if (use_sqk(pp)) {
+                any = true;
+                const int rows = (int)(bnd(pp + 1) - bnd(pp)), nbr = rows + (int)sqk_below(pp);
+                if (chol_dataflow_state_ints(nbr) > SQK_GATE || chol_dataflow_fill_tables(nbr, rows, sqk_tab_host.data() + pp * SQK_TAB, (int)SQK_TAB) < 0) {
+                    gpx_set_error("chol_factor: square launch of %d + %d block rows does not fit its state / table slot", rows, nbr - rows);
+                    return GPX_ERR_STATE;
+                }
+            }
         if (!any) return 0;
-        if (chol_dataflow_table_ints(CHOL_NBP) > SQK_TAB) { gpx_set_error("chol_factor: square-kernel table larger than its slot"); return GPX_ERR_STATE; }
         GPX_HIP(hipMemsetAsync(sqk_buf, 0, sizeof(int) * (size_t)(P * SQK_STATE), s));
-        GPX_TRY(chol_dataflow_upload_tables(CHOL_NBP, sqk_tab(CHOL_NBP), sqk_tab_full, s));
-        if (shorter) GPX_TRY(chol_dataflow_upload_tables((int)(nblk - bnd(P - 1)), sqk_tab(0), sqk_tab_last, s));
+        GPX_HIP(hipMemcpyAsync(sqk_tab(0), sqk_tab_host.data(), sizeof(int) * sqk_tab_host.size(), hipMemcpyHostToDevice, s));
         return 0;
+    };
+    // the rows below panel pp's square have their update (queued on `on` just now): its square launch may solve them
+    auto sqk_open_gate = [&](int64_t pp, hipStream_t on) {
+        if (use_sqk(pp) && sqk_below(pp) > 0) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, on, sqk_gate(pp), 1);
     };
     std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
@@ -671,13 +693,14 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         }
         if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP), s));
         GPX_TRY(sqk_prepare());
+        sqk_open_gate(0, s);   // (the first panel's columns are complete when the factorisation is called)
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
         auto piped = [&](int64_t q) { return s_top && bnd(q + 1) < nblk; };
         for (int64_t q = 0; q < P; ++q) {
             tops[q].stream = piped(q) ? s_top : nullptr;
-            tops[q].r0 = bnd(q + 1);
+            tops[q].r0 = bnd(q + 1) + (use_sqk(q) ? sqk_below(q) : 0);   // (a square launch solves the next square's rows itself)
             tops[q].r1 = nblk;
             tops[q].events = &top_events;
         }
@@ -690,6 +713,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_TRY(sqk_launch(0, 0, bnd(1)));
             tops[0].sq_state = sqk_state(0);
             tops[0].sq_rows = bnd(1);
+            tops[0].sq_nbr = bnd(1) + sqk_below(0);
             if (after_fork) GPX_TRY((*after_fork)());
             if (tops[0].stream && tops[0].r1 > tops[0].r0)
                 for (int64_t j = 0; j < bnd(1); ++j) GPX_TRY(top_column(L, ld, 0, j, Dinv, &tops[0], prof));
@@ -716,8 +740,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             const int64_t K = (B1 - B0) * TILE;
             // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
             //     square before anything else so that the side stream starts early
-            if (piped(p)) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
-            else GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
+            // (a square launch that solved the rows [B1, B2) itself: the square update below needs nothing else -- the column solves of
+            // the rows further down are waited for behind it, in front of the updates that read them)
+            const bool top_late = piped(p) && use_sqk(p) && sqk_below(p) == B2 - B1 && B2 > B1;
+            if (piped(p) && !top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
+            else if (!piped(p)) GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
             // (lower 32 x 32 tiles only: nothing reads the square above its diagonal -- the bulk launches never updated it there)
             static const int sq_lower = [] { const char *e = getenv("GPX_SQ_LOWER"); return e ? atoi(e) : 1; }();
@@ -736,6 +763,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
                 }
             }
+            if (top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
@@ -755,6 +783,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                            K, -1.0, 1.0, 0, s, prof, 0, 0, (narrow_small && use_sqk(p + 1) && p + 1 > 0) ? 1 : 0));
+                if (!handover) sqk_open_gate(p + 1, s);   // panel p+1's columns have their update: its square launch may solve the rows below its square
                 if (piped(p + 1) && !handover) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     if (merged == 0) {
                         // every column solve waits for its own column's narrow tiles (top_column).  Handing the count over as an event
@@ -766,7 +795,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                         GPX_HIP(hipEventRecord(ev_tu[p], s));
                         GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
                     }
-                    if (use_sqk(p + 1)) { tops[p + 1].sq_state = sqk_state(p + 1); tops[p + 1].sq_rows = B2 - B1; }   // (top_column waits for the step itself)
+                    if (use_sqk(p + 1)) {   // (top_column waits for the step itself)
+                        tops[p + 1].sq_state = sqk_state(p + 1);
+                        tops[p + 1].sq_rows = B2 - B1;
+                        tops[p + 1].sq_nbr = B2 - B1 + sqk_below(p + 1);
+                    }
                     else GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }

@@ -71,6 +71,11 @@ struct DflowParams {
     int nside, nkeep;
     unsigned long long *trace;   // GPX_DFLOW_TRACE: [0] = event count, then 8 words per event (kind, a, b, c, t0..t3); null = off
     int trace_cap;
+    // square launches (chol.hip): only the first leaf_steps block columns are factored -- the rows below them (the NEXT diagonal square's
+    // rows) are solved by COL-queue tasks of extra WORK workers; workgroups 1 .. side_first serve the chain queue (0: the hardware-id rule);
+    // gate: a word another stream sets once those rows have received the previous panel's update (null: they are ready at the launch)
+    int leaf_steps, side_first;
+    const int *gate;
 };
 // table layout (ints): chain_off[nbr + 1] | col_off[nbr + 1] | bulk_cum[8][Q + 1] | bulk_mode[Q] | sq_off[Q + 1] | bulk_geo[Q][8][2]
 __device__ __forceinline__ const int *tab_chain(const int *t, const DflowParams &p) { (void)p; return t; }
@@ -231,6 +236,7 @@ __device__ __noinline__ bool run_col(const DflowParams &p, int i, int k, int s, 
         d.add(st_prog(p, i, s), k - 1);
         for (int u = 0; u < 4; ++u) d.add(st_prog(p, k, u), k);
         d.add(st_ver(p, i, k), 8 * q);
+        if (kind == 4 && p.gate) d.add(p.gate, 1);   // rows below a square launch's square: updated by another stream's launch
         if (wait_deps(p, d, true, s_res) < 0) return false;
     }
     const unsigned long long t1 = STAMP(p);
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
             st_agent(p.st + ST_LEAFCU, 1 + (int)(((xcc & 0xf) << 8) | ((hw >> 8) & 0xff)));
         }
         if (bulk_only) return;
-        for (int k = 0; k < p.nbr; ++k) {
+        for (int k = 0; k < p.leaf_steps; ++k) {
             const int q = k / NBP;
             Deps d;
             d.add(st_ver(p, k, k), 8 * q);
@@ -496,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
         int lc = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((lc = ld_agent(p.st + ST_LEAFCU)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < 100000ull) __builtin_amdgcn_s_sleep(2);   // <= 1 ms
-        const bool side = !bulk_only && (int)((hw >> 8) & (unsigned)p.side_mask) == p.side_val;
+        const bool side = !bulk_only && (p.side_first > 0 ? (int)blockIdx.x <= p.side_first : (int)((hw >> 8) & (unsigned)p.side_mask) == p.side_val);
         // ticket: -1 the leaf's mate; side workers count themselves (the chain queue needs at least one: see the launch function)
         s_val = (lc == me) ? -1 : (side ? (1 << 20) + add_agent(p.st + ST_SIDES, 1) : add_agent(p.st + ST_TICKETS, 1));
         s_bad = (int)(xcc & 7);
@@ -731,7 +737,9 @@ int64_t chol_dataflow_table_ints(int64_t nbr)
 // leaf, all of them on the chain queue; exclusive: every workgroup asks for 52 KB of dynamic LDS on top, so that no GEMM workgroup of
 // another launch joins it on its CU.  state_dev[0] then counts the square's finished steps (what its column solves wait for).
 // the task tables of a factorisation of nbr block rows (what the kernel keeps in LDS)
-static void dataflow_tables(int nbr, std::vector<int> &host_tab)
+// first_rows > 0 (square launches): only the first panel, of first_rows block columns, is factored; the block rows below it get their
+// COL tasks for those columns and nothing else
+static void dataflow_tables(int nbr, std::vector<int> &host_tab, int first_rows = 0)
 {
     const int Q = (nbr + NBP - 1) / NBP;
     host_tab.assign((size_t)chol_dataflow_table_ints(nbr), 0);
@@ -740,15 +748,16 @@ static void dataflow_tables(int nbr, std::vector<int> &host_tab)
         const int q = k / NBP, c = k - q * NBP, sqrows = std::min(NBP, nbr - q * NBP);
         const int ncol = 4 * (sqrows - 1 - c);
         const int ndiag = (c + 1 < sqrows) ? 4 : 0;
-        chain[k + 1] = chain[k] + ncol + ndiag;
-        col[k + 1] = col[k] + 4 * std::max(0, nbr - (q * NBP + sqrows));
+        const bool live = first_rows <= 0 || k < first_rows;
+        chain[k + 1] = chain[k] + (live ? ncol + ndiag : 0);
+        col[k + 1] = col[k] + (live ? 4 * std::max(0, nbr - (q * NBP + sqrows)) : 0);
     }
     for (int q = 0; q < Q; ++q) {
         const int sqrows = std::min(NBP, nbr - q * NBP);
-        sq[q + 1] = sq[q] + (q >= 1 ? 2 * 4 * (sqrows * (sqrows + 1) / 2) : 0);   // two parts per slab
+        sq[q + 1] = sq[q] + ((q >= 1 && first_rows <= 0) ? 2 * 4 * (sqrows * (sqrows + 1) / 2) : 0);   // two parts per slab
     }
     for (int q = 0; q < Q; ++q) {
-        const int nt = nbr - (q + 2) * NBP, off = NBP;
+        const int nt = first_rows > 0 ? 0 : nbr - (q + 2) * NBP, off = NBP;
         const int nwg = nt > 0 ? nt * off + nt * (nt + 1) / 2 : 0;
         int m = 1;
         if (nt > 0) {
@@ -776,24 +785,34 @@ static void dataflow_tables(int nbr, std::vector<int> &host_tab)
 
 // tables of an nbr-row factorisation -> tab_dev (chol_dataflow_table_ints(nbr) ints) on stream s: for callers that launch several squares
 // of one shape and zero their state words themselves (launch_chol_dataflow's tab_ready)
-int chol_dataflow_upload_tables(int nbr, int *tab_dev, std::vector<int> &host_tab, hipStream_t s)
+// the tables of a square launch (first_rows columns factored, nbr block rows in all) into dst (host; cap ints): returns the count or -1
+int chol_dataflow_fill_tables(int nbr, int first_rows, int *dst, int cap)
 {
-    if (!chol_dataflow_supported(nbr)) { gpx_set_error("chol_dataflow_upload_tables: unsupported shape (%d block rows)", nbr); return GPX_ERR_BAD_ARG; }
-    dataflow_tables(nbr, host_tab);
-    GPX_HIP(hipMemcpyAsync(tab_dev, host_tab.data(), sizeof(int) * host_tab.size(), hipMemcpyHostToDevice, s));
-    return 0;
+    if (!chol_dataflow_supported(nbr) || first_rows < 1 || first_rows > NBP || first_rows > nbr) return -1;
+    std::vector<int> tab;
+    dataflow_tables(nbr, tab, first_rows < nbr ? first_rows : 0);
+    if ((int)tab.size() > cap) return -1;
+    std::copy(tab.begin(), tab.end(), dst);
+    return (int)tab.size();
 }
 
 // tab_ready: the caller has zeroed the state words and uploaded the tables (chol_dataflow_upload_tables) in front of everything that
 // may look at the state -- a launch that zeroes its own state on ITS stream is only safe when nothing on another stream polls that state
 // before the launch (the square-kernel mode's column solves do: a recycled buffer would show them the previous fit's finished counters)
+// first_rows > 0 (with workers > 0): block columns [c0, c0 + first_rows) are factored and the rows below, up to nb, solved for them by
+// `extra` WORK workers (COL-queue tasks) once *gate is set (null: ready at the launch) -- see DflowParams
 int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *Dinv, double *diag, int *info_dev, int *state_dev,
-                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers, int exclusive, const int *tab_ready)
+                         std::vector<int> &host_tab, unsigned long long limit_ticks, hipStream_t s, int workers, int exclusive, const int *tab_ready,
+                         int first_rows, int extra, const int *gate)
 {
     const int nbr = (int)(nb - c0);
-    if (c0 % NBP || !chol_dataflow_supported(nbr)) { gpx_set_error("launch_chol_dataflow: unsupported shape (nb=%ld, c0=%ld)", (long)nb, (long)c0); return GPX_ERR_BAD_ARG; }
+    if (c0 % NBP || !chol_dataflow_supported(nbr) || (first_rows > 0 && (workers <= 0 || first_rows > NBP || first_rows > nbr))) {
+        gpx_set_error("launch_chol_dataflow: unsupported shape (nb=%ld, c0=%ld, first_rows=%d)", (long)nb, (long)c0, first_rows);
+        return GPX_ERR_BAD_ARG;
+    }
+    if (first_rows >= nbr) { first_rows = 0; extra = 0; }   // nothing below the square
     const int Q = (nbr + NBP - 1) / NBP;
-    dataflow_tables(nbr, host_tab);
+    dataflow_tables(nbr, host_tab, first_rows);
     const int *chain = host_tab.data(), *col = chain + (nbr + 1), *sq = col + (nbr + 1) + 8 * (Q + 1) + Q;
     const int64_t nstate = chol_dataflow_state_ints(nbr);
     const int *tab_dev = tab_ready;
@@ -811,6 +830,10 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
     static const int smask = [] { const char *e = getenv("GPX_DFLOW_SIDE_MASK"); return e ? (int)strtol(e, nullptr, 0) : 0x2f; }();
     static const int sval = [] { const char *e = getenv("GPX_DFLOW_SIDE_VAL"); return e ? (int)strtol(e, nullptr, 0) : 0; }();
     p.side_mask = workers > 0 ? 0 : smask; p.side_val = workers > 0 ? 0 : sval;   // (mask 0: every workgroup is a side worker)
+    p.leaf_steps = first_rows > 0 ? first_rows : nbr;
+    p.side_first = (first_rows > 0 && extra > 0) ? workers : 0;
+    p.gate = first_rows > 0 ? gate : nullptr;
+    if (first_rows <= 0) extra = 0;
     p.limit = limit_ticks;
     static const int nside = getenv("GPX_DFLOW_BULKONLY") ? -7 : 0;
     static const int nkeep = [] { const char *e = getenv("GPX_DFLOW_KEEP"); return e ? atoi(e) : 192; }();
@@ -836,7 +859,7 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
     }
     static const bool attr = [] { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(chol_dataflow_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 52 * 1024); return true; }();
     (void)attr;
-    hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)(workers > 0 ? 1 + workers : grid)), dim3(256), (workers > 0 && exclusive) ? 52 * 1024 : 0, s, p);
+    hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)(workers > 0 ? 1 + workers + extra : grid)), dim3(256), (workers > 0 && exclusive) ? 52 * 1024 : 0, s, p);
     GPX_HIP(hipGetLastError());
     if (trace_path) {
         GPX_HIP(hipStreamSynchronize(s));
@@ -866,7 +889,7 @@ extern "C" int gpx_dev_chol_dataflow(double *L, int64_t ld, int64_t nblk, int64_
     std::vector<int> tab;
     hipStream_t s = (hipStream_t)stream;
     static const unsigned long long lim = [] { const char *e = getenv("GPX_WAIT_LIMIT_MS"); const double ms = e ? atof(e) : 5000.0; return (unsigned long long)(ms * 1e5); }();
-    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s, 0, 0, nullptr);
+    int rc = launch_chol_dataflow(L, ld, nblk, first_block, dinv, diag, info_dev, reinterpret_cast<int *>(stbuf), tab, lim, s, 0, 0, nullptr, 0, 0, nullptr);
     const hipError_t e = hipStreamSynchronize(s);
     dfree(stbuf);
     GPX_TRY(rc);
