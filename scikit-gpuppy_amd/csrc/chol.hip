@@ -216,20 +216,30 @@ struct TopPipe {
     int64_t sq_nbr = 0;                     // block rows the square launch owns (its state layout: the square's + the rows it solves below)
 };
 
+// a one-thread kernel that holds the slice's stream until the trapezoid launch has counted column c's narrow tiles (on the device it runs
+// next to that launch)
+static int colsig_wait(const TopPipe *top, int64_t c)
+{
+    static const bool force_stall = getenv("GPX_TEST_FORCE_STALL") != nullptr;   // test hook: the first wait of the process expires at once
+    static bool forced = false;
+    const bool force = force_stall && !forced;
+    forced = forced || force;
+    hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + c, force ? 0x7fffffff : top->colwant,
+                       force ? 1000ull : wait_limit_ticks(), top->stall);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 // column j of the slice: X_j = (Z_j - X_{B0..j} L[j, B0..j)^T) Dinv_j^T   (left-looking, two small launches on top->stream)
-static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double *Dinv, const TopPipe *top, Profiler *prof)
+// part: 0 both launches; 1 the update only -- it needs the columns before j and row j of the square's factor (chain step j - 1), NOT
+// chain step j: queued in front of the stream's wait for step j it runs underneath that step's leaf, and only the solve (part 2; 13 us)
+// follows the step (the last three column solves of a panel used to trail its chain by 290 us: update 50-67 us + solve per column)
+static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double *Dinv, const TopPipe *top, Profiler *prof, int part = 0)
 {
     double *Zt = L + (top->r0 * TILE) * ld;
     const int64_t M = (top->r1 - top->r0) * TILE;
-    if (top->colsig) {   // a one-thread kernel in front of the column's solve (on the device it runs next to the trapezoid launch)
-        static const bool force_stall = getenv("GPX_TEST_FORCE_STALL") != nullptr;   // test hook: the first wait of the process expires at once
-        static bool forced = false;
-        const bool force = force_stall && !forced;
-        forced = forced || force;
-        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->colsig + (j - B0), force ? 0x7fffffff : top->colwant,
-                           force ? 1000ull : wait_limit_ticks(), top->stall);
-        GPX_HIP(hipGetLastError());
-    }
+    if (top->sq_state && part == 1) return 0;   // (right-looking mode has no early part)
+    if (top->colsig && part != 2) GPX_TRY(colsig_wait(top, j - B0));
     if (top->sq_state) {
         const int64_t B1 = B0 + top->sq_rows;
         hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_steps(), (int)(j - B0 + 1), wait_limit_ticks(), top->stall);
@@ -246,9 +256,10 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
         }
         return 0;
     }
-    if (j > B0)
+    if (j > B0 && part != 2)
         GPX_TRY(launch_gemm_nt(Zt + B0 * TILE, ld, L + (j * TILE) * ld + B0 * TILE, ld, Zt + j * TILE, ld, M, TILE, (j - B0) * TILE,
                                -1.0, 1.0, 0, top->stream, prof));
+    if (part == 1) return 0;
     // (Measured and dropped: the last column's update split into an early K = 768 part behind the solve two steps before and a
     // K = 128 part after the last leaf -- one more launch per panel costs what the shorter tail gains.)
     return launch_gemm_nt(Zt + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, TILE, Zt + j * TILE, ld, M, TILE, TILE, 1.0, 0.0, 0,
@@ -259,7 +270,12 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
                              double *diagL, int *info_dev, hipStream_t s, Profiler *prof, const TopPipe *top = nullptr, int excl = 0)
 {
     // excl: 1 = the step j == B0 runs its leaf exclusively (launch_potrf_leaf), 2 = every step
+    static const int early_update = [] { const char *e = getenv("GPX_TOP_EARLY"); return e ? atoi(e) : 1; }();
     for (int64_t j = j0; j < j1; ++j) {
+        const bool piped = top && top->stream && top->r1 > top->r0;
+        // row j of the square's factor is final once step j - 1 is through (the stream already waits for it): column j's update now,
+        // underneath this step's leaf
+        if (piped && early_update) GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof, 1));
         GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE, info_dev,
                                   (int)(j * TILE), s, prof, excl == 2 || (excl == 1 && j == B0)));
         const int64_t rows_below = B1 - (j + 1);
@@ -281,7 +297,7 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
             top->events->push_back(e);
             GPX_HIP(hipEventRecord(e, s));
             GPX_HIP(hipStreamWaitEvent(top->stream, e, 0));
-            GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof));
+            GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof, early_update ? 2 : 0));
         }
     }
     return 0;

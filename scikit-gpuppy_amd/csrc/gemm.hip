@@ -251,8 +251,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                                                                                      // workgroups on every CU, 64 x 64 tiles one on half of them
     else if (lower_only) GPX_LAUNCH(2, 2);   // the triangular tile enumeration needs square block tiles
     else if (N == TILE) {   // one column tile (all in-place leaves land here): split the rows finer instead
-        static const double one_col_min = [] { const char *e = getenv("GPX_ONECOL_24_MIN"); return e ? atof(e) : SMALL_GRID_TILES / 2; }();
-        if (tiles >= one_col_min) GPX_LAUNCH(2, 4);
+        if (tiles >= SMALL_GRID_TILES / 2) GPX_LAUNCH(2, 4);   // (32-row tiles up to 256 tiles: measured, no difference in the fit)
         else GPX_LAUNCH(1, 4);
     } else GPX_LAUNCH(2, 2);
 #undef GPX_LAUNCH
