@@ -239,7 +239,14 @@ static int top_column(double *L, int64_t ld, int64_t B0, int64_t j, const double
     double *Zt = L + (top->r0 * TILE) * ld;
     const int64_t M = (top->r1 - top->r0) * TILE;
     if (top->sq_state && part == 1) return 0;   // (right-looking mode has no early part)
-    if (top->colsig && part != 2) GPX_TRY(colsig_wait(top, j - B0));
+    if (top->colsig && part != 2) {
+        // left-looking, step j touches column j only; right-looking (square launch) it updates every later column of the slice as
+        // well: the first step waits for ALL of the trapezoid launch's column counters (waiting for column j alone raced with the narrow
+        // tiles of the later columns once the trapezoid launch was queued behind the column solves of the panel before)
+        if (!top->sq_state) GPX_TRY(colsig_wait(top, j - B0));
+        else if (j == B0)
+            for (int64_t c = 0; c < top->sq_rows; ++c) GPX_TRY(colsig_wait(top, c));
+    }
     if (top->sq_state) {
         const int64_t B1 = B0 + top->sq_rows;
         hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, top->stream, top->sq_state + chol_dataflow_word_steps(), (int)(j - B0 + 1), wait_limit_ticks(), top->stall);
