@@ -1345,8 +1345,8 @@ extern "C" int gpx_spd_inverse(const double *K, int64_t n, double *Kinv_out, dou
         if ((rc = dalloc(&Kd, n * n)) || (rc = dalloc(&L, npad * npad)) || (rc = dalloc(&Dinv, nblk * (int64_t)TILE * TILE)) ||
             (rc = dalloc(&diag, npad + 8)) || (rc = dalloc(&Z, npad * npad)) || (rc = dalloc(&Ki, npad * npad)))
             break;
-        if ((e = hipMalloc((void **)&info, sizeof(int))) != hipSuccess) break;
-        if ((e = hipMemsetAsync(info, 0, sizeof(int), s)) != hipSuccess) break;
+        if ((e = hipMalloc((void **)&info, 2 * sizeof(int))) != hipSuccess) break;   // [0] potrf status, [1] stall word (chol_factor)
+        if ((e = hipMemsetAsync(info, 0, 2 * sizeof(int), s)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(Kd, K, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
         hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)npad), dim3(256), 0, s, (const double *)Kd, (long)n, L, (long)npad, 0.0);
         if ((rc = chol_factor(L, npad, nblk, Dinv, diag, info, s, nullptr, nullptr, nullptr))) break;

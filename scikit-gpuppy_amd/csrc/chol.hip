@@ -528,6 +528,30 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
 {
     if (nblk <= CHOL_NBP || s_pan == nullptr) {
         if (after_fork) GPX_TRY((*after_fork)());
+        // Callers without look-ahead streams (SPGP's M x M blocks, gpx_spd_inverse): between 9 and 64 block rows the whole matrix goes to
+        // the persistent dataflow kernel (dflow.hip) -- a 2048 x 2048 factorisation is a chain of 16 steps, 1.0 ms there against 2.2 ms
+        // of dependent launches.  Its in-kernel waits are bounded; one that expires (it never has) is reported, not retried: the
+        // matrix is overwritten by then.  The call synchronises the stream (the kernel's state words are freed here).
+        static const int small_df = [] { const char *e = getenv("GPX_DFLOW_SMALL"); return e ? atoi(e) : 1; }();
+        if (nblk > CHOL_NBP && nblk <= 64 && small_df && !g_force_plain && chol_dataflow_supported(nblk)) {
+            double *st = nullptr;
+            GPX_TRY(dalloc(&st, (chol_dataflow_state_ints(nblk) + chol_dataflow_table_ints(nblk)) / 2 + 2));
+            std::vector<int> tab;
+            int st_host[2] = {0, 0};
+            hipError_t e = hipMemsetAsync(info_dev + 1, 0, sizeof(int), s);
+            int rc = e == hipSuccess ? launch_chol_dataflow(L, ld, nblk, 0, Dinv, diagL, info_dev, reinterpret_cast<int *>(st), tab, wait_limit_ticks(), s, 0, 0) : 0;
+            if (e == hipSuccess && !rc) e = hipMemcpyAsync(st_host, info_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
+            const hipError_t e2 = hipStreamSynchronize(s);
+            dfree(st);
+            GPX_TRY(rc);
+            GPX_HIP(e);
+            GPX_HIP(e2);
+            if (st_host[1]) {
+                gpx_set_error("factorisation of a %ld-row block: an in-kernel hand-off timed out (GPX_WAIT_LIMIT_MS); GPX_DFLOW_SMALL=0 selects the launch chain",
+                              (long)(nblk * TILE));
+                return GPX_ERR_STATE;
+            }
+        } else
         GPX_TRY((nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                    : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof));
         if (panel_final) GPX_TRY((*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true, nullptr));

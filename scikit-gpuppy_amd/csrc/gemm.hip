@@ -220,8 +220,8 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2.
     // Work = the flops issued: a triangular operand halves the contraction (sum over tile rows / columns of their length).
     const double kfrac = tri ? 0.5 * (1.0 + (double)TILE / (double)K) : 1.0;
-    ProfScope ps(prof, s, tiles >= SMALL_GRID_TILES ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K * kfrac,
-                 tiles >= SMALL_GRID_TILES ? 1 : 2);
+    const bool dominant = tiles >= SMALL_GRID_TILES && !small_tiles;   // (small_tiles: such a launch runs the 64 x 64-tile kernel)
+    ProfScope ps(prof, s, dominant ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K * kfrac, dominant ? 1 : 2);
     const bool in_place = (C == A || C == B);   // in-place TRSM leaves: exactly one column tile per row block
     if (in_place && N != TILE) {
         gpx_set_error("launch_gemm_nt: in-place product needs N == %d", TILE);
