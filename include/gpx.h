@@ -108,6 +108,11 @@ int gpx_solve(gpx_handle *h, const double *B, int nrhs, double *Linv_B_out, doub
 int gpx_chol_mul(gpx_handle *h, const double *Z, int nrhs, double *out);
 int gpx_kinv(gpx_handle *h, double *Kinv_out);      /* K^-1 [n,n], materialised lazily on device
                                                        (GaussianProcess.Kinv attribute, :41, :152-164) */
+/* rows [r0, r1) of K^-1 alone: [r1 - r0, n]; r0 a multiple of 128, r1 a multiple of 128 or n.  What a rank of the row-sharded
+ * propagation (gpx_propagate_approx_rows / gpx_propagate_exact_rows; the reference's loops over all of Kinv,
+ * skgpuppy/UncertaintyPropagation.py:412-481, 343-375, split by rows) builds instead of the whole matrix: E^T L^-T L^-1 for the
+ * panel's unit rows, 2 (r1 - r0) N^2 flop and three panel-sized buffers.  The whole matrix is used when it already exists. */
+int gpx_kinv_rows(gpx_handle *h, int64_t r0, int64_t r1, double *Kinv_rows_out);
 int gpx_chol(gpx_handle *h, double *L_out);         /* lower Cholesky factor [n,n] (zeros above the diagonal) */
 int gpx_chol_rows(gpx_handle *h, int64_t r0, int64_t r1, double *L_out);   /* rows [r0,r1) of it: [r1-r0, n] */
 

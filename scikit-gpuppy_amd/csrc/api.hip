@@ -429,7 +429,7 @@ extern "C" void gpx_free(gpx_handle *h)
     h->prof.destroy();
     h->tri.release();
     if (h->external_factor) { h->L = nullptr; h->Dinv = nullptr; h->diagL = nullptr; }
-    double *bufs[] = {h->Ksrc, h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->Z, h->small, h->V, h->KV};
+    double *bufs[] = {h->Ksrc, h->x, h->xs_w, h->sw, h->wdev, h->L, h->Dinv, h->diagL, h->t, h->y, h->alpha, h->Kinv, h->KinvRows, h->Z, h->small, h->V, h->KV};
     for (double *p : bufs)
         if (p) dfree(p);
     if (h->info_dev) dfree(h->info_dev);
@@ -875,6 +875,60 @@ static int ensure_kinv(gpx_handle *h)
     return 0;
 }
 
+// Rows [row0, row1) (multiples of 128, row1 <= npad) of K^-1 for the row-sharded propagation: the whole matrix if it exists or if the
+// range is all of it, otherwise a row PANEL built alone (TriSolver::kinv_rows: 2 m N^2 flop, three m x N buffers) and kept until another
+// range is asked for.  Returns in *base a pointer that is indexed with ABSOLUTE row numbers (base + i * npad is row i).
+static int ensure_kinv_rows(gpx_handle *h, int64_t row0, int64_t row1, const double **base)
+{
+    const int64_t np = h->npad;
+    static const int panel_env = [] { const char *e = getenv("GPX_KINV_ROWS"); return e ? atoi(e) : 1; }();
+    // a panel that does not contain the range is replaced by one over the hull of both (a rank's Approx and Exact shards differ: equal
+    // rows against equal area of the triangle); a hull of three quarters of the rows or more is not worth a panel
+    if (h->KinvRows && !(h->kr0 <= row0 && row1 <= h->kr1)) { row0 = std::min(row0, h->kr0); row1 = std::max(row1, h->kr1); }
+    if (!h->Kinv && 4 * (row1 - row0) < 3 * np && panel_env && h->tri.ready() && row1 > row0) {
+        if (!(h->KinvRows && h->kr0 <= row0 && row1 <= h->kr1)) {
+            hipStream_t s = h->stream;
+            if (h->KinvRows) { GPX_HIP(hipStreamSynchronize(s)); dfree(h->KinvRows); h->KinvRows = nullptr; }
+            const int64_t m = row1 - row0;
+            double *X = nullptr, *Zb = nullptr, *Yb = nullptr, *Tb = nullptr;
+            int rc = 0;
+            if ((rc = dalloc(&X, m * np)) || (rc = dalloc(&Zb, m * np)) || (rc = dalloc(&Yb, m * np)) || (rc = dalloc(&Tb, (int64_t)CHOL_PANEL_COLS * np)) ||
+                (rc = h->tri.kinv_rows(row0, row1, X, Zb, Yb, Tb, s, &h->prof))) {
+                (void)hipStreamSynchronize(s);
+                dfree(X); dfree(Zb); dfree(Yb); dfree(Tb);
+                return rc;
+            }
+            const hipError_t e = hipStreamSynchronize(s);
+            dfree(Zb); dfree(Yb); dfree(Tb);
+            if (e != hipSuccess) { dfree(X); gpx_set_error("K^-1 row panel failed: %s", hipGetErrorString(e)); return GPX_ERR_HIP; }
+            h->KinvRows = X; h->kr0 = row0; h->kr1 = row1;
+        }
+        *base = reinterpret_cast<const double *>(reinterpret_cast<uintptr_t>(h->KinvRows) - (uintptr_t)(sizeof(double) * (size_t)(h->kr0 * np)));
+        return 0;
+    }
+    if (h->KinvRows && !h->Kinv) { GPX_HIP(hipStreamSynchronize(h->stream)); dfree(h->KinvRows); h->KinvRows = nullptr; h->kr0 = h->kr1 = 0; }
+    GPX_TRY(ensure_kinv(h));
+    *base = h->Kinv;
+    return 0;
+}
+
+// test / tool access: rows [row0, row1) of K^-1 (multiples of 128 or n) -> out [row1 - row0, n] (host or device), built as the
+// row-sharded propagation builds them
+extern "C" int gpx_kinv_rows(gpx_handle *h, int64_t row0, int64_t row1, double *out)
+{
+    CHECK_H(h);
+    if (!out || row0 < 0 || row1 <= row0 || row1 > h->n || row0 % TILE || (row1 % TILE && row1 != h->n)) {
+        gpx_set_error("gpx_kinv_rows: bad arguments (rows [%ld, %ld) of %ld)", (long)row0, (long)row1, (long)h->n);
+        return GPX_ERR_BAD_ARG;
+    }
+    const double *base = nullptr;
+    GPX_TRY(ensure_kinv_rows(h, row0, round_up(row1, TILE), &base));
+    GPX_HIP(hipMemcpy2DAsync(out, sizeof(double) * h->n, base + row0 * h->npad, sizeof(double) * h->npad, sizeof(double) * h->n, (size_t)(row1 - row0),
+                             hipMemcpyDefault, h->stream));
+    GPX_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
 extern "C" int gpx_kinv(gpx_handle *h, double *Kinv_out)
 {
     CHECK_H(h);
@@ -1063,7 +1117,8 @@ extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const d
     const int d = h->d;
     const int64_t np = h->npad;
     hipStream_t s = h->stream;
-    GPX_TRY(ensure_kinv(h));
+    const double *kbase = nullptr;
+    if (row1 > row0) GPX_TRY(ensure_kinv_rows(h, row0, round_up(row1, TILE), &kbase));
     GPX_TRY(ensure_prop_buffers(h));
     h->have_u = false;   // KV is about to hold a row panel only
     double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
@@ -1078,7 +1133,7 @@ extern "C" int gpx_propagate_approx_rows(gpx_handle *h, const double *u, const d
     const int64_t r1p = round_up(row1, TILE), len = row1 > row0 ? r1p - row0 : 0;   // rows past n are padding: V and tr are zero there
     const int npair = 4 + 2 * d;
     if (len > 0) {
-        GPX_TRY(launch_kinv_pass(h->Kinv + row0 * np, np, np, d + 1, h->V, h->KV + row0, s, &h->prof, len));
+        GPX_TRY(launch_kinv_pass(kbase + row0 * np, np, np, d + 1, h->V, h->KV + row0, s, &h->prof, len));
         std::vector<std::pair<const double *, const double *>> pr;
         const double *C = h->V + row0, *KC = h->KV + row0, *al = h->alpha + row0, *trr = tr + row0;
         pr.push_back({al, C});
@@ -1219,7 +1274,11 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     const int d = h->d;
     const int64_t np = h->npad;
     hipStream_t s = h->stream;
-    if (want_var) GPX_TRY(ensure_kinv(h));
+    const double *kbase = nullptr;
+    if (want_var) {
+        if (row1 > 0) GPX_TRY(ensure_kinv_rows(h, row0, round_up(row1, TILE), &kbase));   // a rank's row panel (gpx_propagate_exact_rows)
+        else { GPX_TRY(ensure_kinv(h)); kbase = h->Kinv; }
+    }
     GPX_TRY(ensure_prop_buffers(h));
     double uh[GPX_MAX_D], Sh[GPX_MAX_D * GPX_MAX_D];
     GPX_TRY(fetch_small(uh, u, d));
@@ -1262,7 +1321,7 @@ static int exact_common(gpx_handle *h, const double *u, const double *Sigma, boo
     pr.push_back({h->alpha + r0, lm + r0});
     if (!rc && r1 > r0) rc = launch_dot_pairs(pr, r1 - r0, outd, s);
     else if (!rc) er = hipMemsetAsync(outd, 0, sizeof(double) * 2, s);
-    if (!rc && want_var) rc = launch_exact_sum(h->Kinv, np, np, d, h->alpha, aT, bT, e, F, partial, outd + 1, s, &h->prof, r0, ranged ? r1 : 0);
+    if (!rc && want_var) rc = launch_exact_sum(kbase, np, np, d, h->alpha, aT, bT, e, F, partial, outd + 1, s, &h->prof, r0, ranged ? r1 : 0);
     double o[2] = {0, 0};
     if (!rc) {
         er = hipMemcpyAsync(o, outd, sizeof(double) * 2, hipMemcpyDeviceToHost, s);

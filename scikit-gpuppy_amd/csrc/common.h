@@ -104,6 +104,8 @@ struct TriSolver {
     // B [nrhs][ldb] (right-hand sides as rows, nrhs <= 32) -> Yout = L^-1 B and / or Aout = L^-T L^-1 B (null = skip)
     int solve(const double *B, int64_t ldb, int nrhs, double *Yout, double *Aout, hipStream_t s, Profiler *prof);
     int mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hipStream_t s);   // OUT = L B (rows, nrhs <= 32)
+    // X [r1 - r0, npad] <- rows [r0, r1) of K^-1 without the rest of it (multiples of 128); Zb, Yb: scratch of X's shape, Tb: [1024, npad]
+    int kinv_rows(int64_t r0, int64_t r1, double *X, double *Zb, double *Yb, double *Tb, hipStream_t s, Profiler *prof) const;
     void release();
     bool ready() const { return Pl != nullptr; }
 };
@@ -135,6 +137,8 @@ struct gpx_handle {
     double *alpha = nullptr;    // [npad] K^-1 t
     TriSolver tri;              // few-right-hand-side solves against L (alpha, the propagation right after a fit)
     double *Kinv = nullptr;     // [npad, npad] lazily materialised
+    double *KinvRows = nullptr; // [kr1 - kr0, npad]: a row panel of K^-1 alone (the row-sharded propagation; api.hip, ensure_kinv_rows)
+    int64_t kr0 = 0, kr1 = 0;
     int *info_dev = nullptr;    // [0] potrf info (1-based failing column, 0 = ok)
     double logdet = 0;
     bool have_logdet = false;

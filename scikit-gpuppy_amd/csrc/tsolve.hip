@@ -489,3 +489,59 @@ int build_kinv_from_solver(const TriSolver *ts, double *Z, double *Kinv, hipStre
     GPX_TRY(launch_gemm_nt(Z, npad, Z, npad, Kinv, npad, npad, npad, npad, 1.0, 0.0, 1, s, prof, 1));
     return launch_symmetrize_lower(Kinv, npad, npad, s);
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// A ROW PANEL of K^-1 without the rest of it (the row-sharded propagation of distributed.py: rank r passes over rows
+// [r0, r1) of K^-1 only -- skgpuppy/UncertaintyPropagation.py:412-481 loops over all of Kinv on one host):
+//     K^-1[r0:r1, :] = E^T L^-T L^-1 ,   E = columns r0..r1 of the identity
+// with the right-hand sides stored as ROWS (m = r1 - r0 of them):
+//   1.  Y = E^T L^-T : the many-right-hand-side solve of estimate_many (trsm_right_lt_squares), started at r0's square
+//       (everything left of it stays zero);
+//   2.  X = Y L^-1   : the mirror image, squares from the last to the first, left-looking:
+//           X[:, p] = (Y[:, p] - X[:, > p] L[> p, p]) inv(L_pp)
+//       The product with L[> p, p] is not an NT product (the contraction runs down L's columns): the panel's 1024 columns are
+//       transposed into T (1024 x rows below, one pass over the panel) and the update is gemm_nt(X[:, > p], T); the leaf is the
+//       product with inv(L_pp)^T's rows (Pz, upper triangular: the zero triangle is skipped).
+// 2 m N^2 flop on 128 x 128 tiles and three m x N panels instead of 2 N^3 / 3 flop and two N x N matrices: at m = N / R the
+// work per rank falls from 0.67 N^3 to 2 N^3 / R and the memory with it.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ts_unit_rows_kernel(double *__restrict__ Z, long ld, long r0)
+{
+    const long i = blockIdx.x;
+    if (threadIdx.x == 0) Z[i * ld + r0 + i] = 1.0;
+}
+
+// dst[c][r] = src[r][c] for r < rows, c < cols (both multiples of 32)
+__global__ __launch_bounds__(256) void ts_transpose_kernel(const double *__restrict__ src, long lds_, double *__restrict__ dst, long ldd)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long r0 = 32L * blockIdx.y, c0 = 32L * blockIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tile[ty + 8 * q][tx] = src[(r0 + ty + 8 * q) * lds_ + c0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[(c0 + ty + 8 * q) * ldd + r0 + tx] = tile[tx][ty + 8 * q];
+}
+
+// X [m, npad] <- rows [r0, r1) of K^-1 (r0, r1 multiples of 128, r1 <= npad); Zb, Yb: scratch [m, npad] each, T: scratch [1024, npad]
+int TriSolver::kinv_rows(int64_t r0, int64_t r1, double *X, double *Zb, double *Yb, double *Tb, hipStream_t s, Profiler *prof) const
+{
+    if (!Pl || r0 < 0 || r1 <= r0 || r1 > npad || r0 % TILE || r1 % TILE) { gpx_set_error("TriSolver::kinv_rows: bad range or solver not prepared"); return GPX_ERR_BAD_ARG; }
+    const int64_t m = r1 - r0, p0 = r0 / PB;
+    GPX_HIP(hipMemsetAsync(Zb, 0, sizeof(double) * m * npad, s));
+    GPX_HIP(hipMemsetAsync(Yb, 0, sizeof(double) * m * npad, s));
+    hipLaunchKernelGGL(ts_unit_rows_kernel, dim3((unsigned)m), dim3(64), 0, s, Zb, (long)npad, (long)r0);
+    GPX_HIP(hipGetLastError());
+    GPX_TRY(trsm_right_lt_squares(Zb, Yb, npad, m, this, p0, P, s, prof));
+    for (int64_t p = P - 1; p >= 0; --p) {
+        const int64_t k0 = p * PB, Kp = std::min<int64_t>(PB, npad - k0), c1 = k0 + Kp, Krem = npad - c1;
+        if (Krem > 0) {
+            hipLaunchKernelGGL(ts_transpose_kernel, dim3((unsigned)(Kp / 32), (unsigned)(Krem / 32)), dim3(256), 0, s, L + c1 * ld + k0, (long)ld, Tb, (long)npad);
+            GPX_HIP(hipGetLastError());
+            GPX_TRY(launch_gemm_nt(X + c1, npad, Tb, npad, Yb + k0, npad, m, Kp, Krem, -1.0, 1.0, 0, s, prof));
+        }
+        GPX_TRY(launch_gemm_nt(Yb + k0, npad, Pz + p * (int64_t)PB * PB, PB, X + k0, npad, m, Kp, Kp, 1.0, 0.0, 0, s, prof, 0, GEMM_TRI_B_UPPER));
+    }
+    return 0;
+}

@@ -74,6 +74,12 @@ class _DeviceModel(object):
         _gpx.check(_gpx.lib.gpx_kinv(self.handle, _gpx.ptr(out)), "gpx_kinv")
         return out
 
+    def kinv_rows(self, r0, r1):
+        """rows [r0, r1) of K^-1 built alone (what a rank of the row-sharded propagation holds)"""
+        out = np.empty((r1 - r0, self.n))
+        _gpx.check(_gpx.lib.gpx_kinv_rows(self.handle, r0, r1, _gpx.ptr(out)), "gpx_kinv_rows")
+        return out
+
     def chol(self):
         out = np.empty((self.n, self.n))
         _gpx.check(_gpx.lib.gpx_chol(self.handle, _gpx.ptr(out)), "gpx_chol")

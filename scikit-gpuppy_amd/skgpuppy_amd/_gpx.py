@@ -56,6 +56,7 @@ SIGNATURES = {
     "gpx_kinv": (_int, [_hp, _dp]),
     "gpx_chol": (_int, [_hp, _dp]),
     "gpx_chol_rows": (_int, [_hp, _i64, _i64, _dp]),
+    "gpx_kinv_rows": (_int, [_hp, _i64, _i64, _dp]),
     "gpx_cjh": (_int, [_hp, _dp, _dp, _dp, _dp]),
     "gpx_propagate_approx": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 4),
     "gpx_propagate_approx_rows": (_int, [_hp, _dp, _dp, _i64, _i64, _dp]),

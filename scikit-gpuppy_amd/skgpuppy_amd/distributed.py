@@ -611,8 +611,9 @@ class ShardedGaussianProcess(object):
             triangular solver on ITS vectors against its copy of the factor (gpx_propagate_approx_rhs).  No rank ever
             materialises K^-1 (34 GB and ~3 s of N^3 work per rank at N = 65536).
         via="kinv": rank r passes over its row panel of K^-1 only ((K^-1 v)_i and every quadratic form are sums over the rows;
-            gpx_propagate_approx_rows).  K^-1 is built per rank on first use: the path for MANY propagations on one fit
-            (inverse propagation, design studies), where each call then reads 1/R of K^-1 per GPU."""
+            gpx_propagate_approx_rows).  Only that ROW PANEL of K^-1 is built, on first use (E^T L^-T L^-1 for the panel's unit
+            rows: 2 N^3 / R flop and three N / R x N buffers per rank instead of 2 N^3 / 3 and two N x N matrices): the path for
+            MANY propagations on one fit (inverse propagation, design studies), where each call then reads 1/R of K^-1 per GPU."""
         import torch
         import torch.distributed as dist
         from . import _gpx

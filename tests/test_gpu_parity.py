@@ -1010,6 +1010,50 @@ def test_kinv_with_inverted_squares_as_leaves(N):
     np.testing.assert_allclose(K.dot(Kinv), np.eye(N), rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("N,ranges", [(2500, [(0, 1024), (1024, 2048), (128, 2432), (2432, 2500)]), (4224, [(1152, 3200), (3072, 4224)])])
+def test_kinv_row_panel_equals_rows_of_the_whole_inverse(N, ranges):
+    """gpx_kinv_rows (TriSolver::kinv_rows): a row panel of K^-1 built alone -- E^T L^-T by the many-right-hand-side solve, then the
+    mirror-image sweep through transposed panels of L -- against numpy's inverse of the oracle Gram: panels that start / end inside a
+    1024 square, cover several squares, and reach into the padding of the last one; then the row-sharded propagations that read it."""
+    d = 3
+    rng = np.random.RandomState(5 + N)
+    x = rng.uniform(0, 10, (N, d))
+    t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N)
+    theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+    ref = np.linalg.inv(orc.gram(x, theta))
+    scale = np.abs(ref).max()
+    for r0, r1 in ranges:
+        gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())     # a fresh handle: no whole K^-1 to fall back on
+        rows = gp._dev().kinv_rows(r0, r1)
+        np.testing.assert_allclose(rows, ref[r0:r1], rtol=0, atol=1e-7 * scale)
+        gp._dev().close()
+    # the partial sums of the row-sharded propagation from panels alone add up to the single-call result
+    u, S = np.full(d, 5.0), 0.01 * np.eye(d)
+    cuts = [0] + [r1 for _r0, r1 in ranges if r1 < N][:1] + [N]
+    cuts = sorted(set(c - c % 128 if c < N else c for c in cuts))
+    def approx_rows(g, a, b):
+        part = np.zeros(4 + 2 * d)
+        _gpx.check(_gpx.lib.gpx_propagate_approx_rows(g._dev().handle, _gpx.ptr(u), _gpx.ptr(S), a, b, _gpx.ptr(part)), "approx_rows")
+        return part
+
+    def exact_rows(g, a, b):
+        part = np.zeros(3)
+        _gpx.check(_gpx.lib.gpx_propagate_exact_rows(g._dev().handle, _gpx.ptr(u), _gpx.ptr(S), a, b, _gpx.ptr(part)), "exact_rows")
+        return part
+
+    parts_a, parts_e = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):     # one handle per "rank": each builds its own panel, Approx first, then Exact on the same rows
+        g = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+        parts_a.append(approx_rows(g, a, b))
+        parts_e.append(exact_rows(g, a, b))
+        g._dev().close()
+    whole = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    wa = approx_rows(whole, 0, N)
+    we = exact_rows(whole, 0, N)
+    np.testing.assert_allclose(np.sum(parts_a, axis=0), wa, rtol=1e-9, atol=1e-9 * np.abs(wa).max())
+    np.testing.assert_allclose(np.sum(parts_e, axis=0)[:2], np.asarray(we)[:2], rtol=1e-9, atol=1e-12)
+
+
 @pytest.mark.parametrize("N,d,k", [(64, 2, 3), (1300, 3, 33)])
 def test_get_realisation_is_L_times_z(N, d, k):
     """f4 (GaussianProcess.py:44-57): the draw is t = L z with K = cov_matrix(x, theta) assembled and factored on the GPU
