@@ -38,7 +38,8 @@ def test_device_is_gfx950_and_library_loaded():
     assert tf.value > 10.0          # fp64 MFMA is alive (vendor peak 78.6 TFLOP/s)
 
 
-@pytest.mark.parametrize("M,N,K,lower", [(128, 128, 16, 0), (256, 128, 48, 0), (384, 256, 128, 0), (256, 256, 272, 1)])
+@pytest.mark.parametrize("M,N,K,lower", [(128, 128, 16, 0), (256, 128, 48, 0), (384, 256, 128, 0), (256, 256, 272, 1),
+                                          (1024, 1024, 1024, 1)])   # the last one: <= 40 lower tiles with a long contraction -> the 32 x 32-tile variant
 def test_gemm_nt_against_numpy(M, N, K, lower):
     rng = np.random.RandomState(M + N + K)
     A = rng.randn(M, K)
@@ -1089,7 +1090,7 @@ def test_get_realisation_distribution():
     assert abs(S - K).max() < 5 * 2.01 * np.sqrt(2.0 / 4000)
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 384, 48), (384, 1408, 64), (2048, 3072, 32)])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 48), (384, 1408, 64), (2048, 3072, 32), (512, 1024, 640)])   # (the last: 32 x 32 tiles with full columns on the left)
 def test_gemm_nt_trapezoid(M, N, K):
     """lower_only with N > M: the first N - M columns are full, the remaining square is lower-triangular by 128-tiles
     (the Cholesky's merged trailing update); tiles above that staircase must stay untouched."""
