@@ -79,16 +79,32 @@ __global__ __launch_bounds__(256) void trace_kernel(const double *__restrict__ x
 
 // out[p] = sum_i P_p[i] Q_p[i], one workgroup per pair, fixed summation order (deterministic)
 struct DotPairs { const double *p[80]; const double *q[80]; };
-__global__ __launch_bounds__(256) void dot_pairs_kernel(DotPairs pairs, long n, double *__restrict__ out)
+// (1024 threads, 16-byte loads where the operands allow them: a pair of 16384 entries is 8 dependent loads per thread -- the
+// 256-thread, 8-byte version was a chain of 64 and took 22 us, a quarter of a propagation call's overhead)
+__global__ __launch_bounds__(1024) void dot_pairs_kernel(DotPairs pairs, long n, double *__restrict__ out)
 {
-    __shared__ double ws[4];
+    __shared__ double ws[16];
     const double *P = pairs.p[blockIdx.x], *Q = pairs.q[blockIdx.x];
-    double s = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) s = fma(P[i], Q[i], s);
-    s = wave_sum_p(s);
+    double s0 = 0.0, s1 = 0.0;
+    const bool wide = !(n & 1) && !(((uintptr_t)P | (uintptr_t)Q) & 15);      // uniform per workgroup
+    if (wide) {
+        const long half = n >> 1;
+        for (long i = threadIdx.x; i < half; i += 1024) {
+            const v2d a = reinterpret_cast<const v2d *>(P)[i], b = reinterpret_cast<const v2d *>(Q)[i];
+            s0 = fma(a.x, b.x, s0);
+            s1 = fma(a.y, b.y, s1);
+        }
+    } else
+        for (long i = threadIdx.x; i < n; i += 1024) s0 = fma(P[i], Q[i], s0);
+    double s = wave_sum_p(s0 + s1);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += ws[w];
+        out[blockIdx.x] = t;
+    }
 }
 
 int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>> &pr, long n, double *out_dev,
@@ -99,7 +115,7 @@ int launch_dot_pairs(const std::vector<std::pair<const double *, const double *>
         DotPairs dp;
         size_t cnt = std::min<size_t>(80, pr.size() - done);
         for (size_t i = 0; i < cnt; ++i) { dp.p[i] = pr[done + i].first; dp.q[i] = pr[done + i].second; }
-        hipLaunchKernelGGL(dot_pairs_kernel, dim3((unsigned)cnt), dim3(256), 0, s, dp, n, out_dev + done);
+        hipLaunchKernelGGL(dot_pairs_kernel, dim3((unsigned)cnt), dim3(1024), 0, s, dp, n, out_dev + done);
         done += cnt;
     }
     GPX_HIP(hipGetLastError());
