@@ -798,6 +798,10 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
                                    -1.0, 1.0, sq_lower, s, prof));
             GPX_HIP(hipEventRecord(ev_next[p], s));
+            // from the first tail panel that runs as a square launch the chain no longer lives on the reserved CUs (a square launch brings
+            // its own: one workgroup per CU): the blockers would only keep 32 CUs from the short bulk launches beside it
+            static const int sqk_release = [] { const char *e = getenv("GPX_SQK_RELEASE"); return e ? atoi(e) : 1; }();
+            if (sqk_release && sqk_from < 0 && p + 1 > 0 && use_sqk(p + 1)) release_blockers(s);
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             if (!handover) {
@@ -850,6 +854,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     else GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
+                // (measured: this short bulk launch on 64 x 64 tiles beside a square launch -- no difference)
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                            (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
