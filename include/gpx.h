@@ -154,6 +154,14 @@ int gpx_propagate_exact(gpx_handle *h, const double *u, const double *Sigma, dou
  * nc2 }; summed over the row panels: mean = p0, var = v + vt - nc2 p1 - p0^2.  Same row alignment as gpx_propagate_approx_rows. */
 int gpx_propagate_exact_rows(gpx_handle *h, const double *u, const double *Sigma, int64_t row0, int64_t row1, double *partial_out);
 int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *mean);
+/* a14 for ANY operator: the reference's UncertaintyPropagationExact.propagate_GA talks to the GP only through _get_beta, _get_W_inv,
+ * _inv_cov_matrix, _covariance and x (skgpuppy/UncertaintyPropagation.py:269-290, :323-379), so it runs -- and returns numbers -- for a
+ * Covariance subclass with its own kernel.  C_ux [n] = cov(u, x_i) and cuu = cov(u, u) come from the operator's scalar kernel (host,
+ * N calls as in the reference), x [n, d] and w [d] = diag(_get_W_inv()) are handle-free HOST arrays, u [d] / Sigma [d, d] host;
+ * K^-1 and beta come from h (any fitted handle, e.g. gpx_fit_matrix) or, with h == NULL, from explicit Kinv [n, n] / beta [n].
+ * mean WITHOUT meant; var = cuu - sum_ij (Kinv_ij - beta_i beta_j) C_i C_j corr2_ij - mean^2. */
+int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d, const double *w,
+                               const double *C_ux, const double *u, const double *Sigma, double cuu, double *mean, double *var);
 
 /* ---- "next" row f1: hyper-parameter likelihood at the handle's theta
  * (Covariance._negativeloglikelihood / _d_nll_d_theta, skgpuppy/Covariance.py:197-216, :266-282, :605-657) ----

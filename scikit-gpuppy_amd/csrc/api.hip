@@ -34,6 +34,10 @@ int launch_exact_build(const double *x, int64_t n, int64_t npad, int d, const do
                        const double *Ls_dev, const double *dinv_diag_dev, double v, double vt, double nc1, double *aT,
                        double *bT, double *e, double *F, double *lm, hipStream_t s);
 
+int launch_exact_build_generic(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *Ls_dev,
+                               const double *dinv_diag_dev, const double *C_dev, double nc1, double *aT, double *bT, double *e, double *F,
+                               double *lm, hipStream_t s);
+
 // ---- error text -----------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 static thread_local int g_device = 0;   // per host thread: gpx_set_device selects the device of handles created by THIS thread
@@ -418,8 +422,9 @@ extern "C" int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int6
 }
 
 // ---- fit ---------------------------------------------------------------------------------------
-// priorities of the fit's streams (experiment switches: GPX_MAIN_PRIO, GPX_SIDE_PRIO)
-static int main_stream_prio() { static const int v = [] { const char *e = getenv("GPX_MAIN_PRIO"); return e ? atoi(e) : 0; }(); return v; }
+// priority class of the fit's streams: main stream normal, chain and column-solve streams high (GPX_SIDE_PRIO=0: test hook that puts
+// all of them into one class, so that they share hardware queues -- tests/test_gpu_parity.py, fall-back schedules)
+static int main_stream_prio() { return 0; }
 static int side_stream_prio() { static const int v = [] { const char *e = getenv("GPX_SIDE_PRIO"); return e ? atoi(e) : 1; }(); return v; }
 extern "C" void gpx_free(gpx_handle *h)
 {
@@ -469,11 +474,7 @@ static int factor_once(gpx_handle *h, double add_diag, int *info_host)
         // there shares the chip with those chains (the forward updates stream the factor at HBM rate, the chain's small GEMMs slow
         // down: chains of 0.7-0.8 ms grew to 0.9-1.1 ms when the catching-up started with four panels left, and the fit gained
         // nothing).  So: up to eight panels per call once a single panel is left, the rest with the last calls.
-        static const std::array<int, 5> budget = [] {
-            std::array<int, 5> b = {1 << 20, 8, 0, 0, 0};
-            if (const char *e = getenv("GPX_RIDE_BUDGET")) (void)sscanf(e, "%d,%d,%d,%d", &b[1], &b[2], &b[3], &b[4]);   // panels per call with 1..4 panels left
-            return b;
-        }();
+        static const std::array<int, 5> budget = {1 << 20, 8, 0, 0, 0};   // panels per call with 1..4 panels left
         if (!last && (!fit_ride_enabled() || slack > 4)) return 0;
         const int64_t upto = last ? p_final + 1 : std::min<int64_t>(p_final + 1, pending + budget[slack]);
         if (upto > pending) {
@@ -862,9 +863,8 @@ static int ensure_kinv(gpx_handle *h)
     GPX_TRY(dalloc(&K, h->npad * h->npad));
     int rc = 0;
     // Z = L^-T (upper triangular, structured recursion) ; Kinv = Z Z^T = L^-T L^-1 (lower strips, then mirrored)
-    // (GPX_KINV_LEAF128=1: the 128-column leaves of chol.hip, which handles without a prepared solver use anyway)
-    static const int leaf128 = [] { const char *e = getenv("GPX_KINV_LEAF128"); return e ? atoi(e) : 0; }();
-    if ((rc = (h->tri.ready() && !leaf128) ? build_kinv_from_solver(&h->tri, h->Z, K, s, &h->prof)
+    // (handles without a prepared solver: the 128-column leaves of chol.hip)
+    if ((rc = h->tri.ready() ? build_kinv_from_solver(&h->tri, h->Z, K, s, &h->prof)
                                            : build_kinv_from_factor(h->L, h->npad, h->nblk, h->Dinv, h->Z, K, s, &h->prof))) {
         dfree(K);
         return rc;
@@ -881,11 +881,10 @@ static int ensure_kinv(gpx_handle *h)
 static int ensure_kinv_rows(gpx_handle *h, int64_t row0, int64_t row1, const double **base)
 {
     const int64_t np = h->npad;
-    static const int panel_env = [] { const char *e = getenv("GPX_KINV_ROWS"); return e ? atoi(e) : 1; }();
     // a panel that does not contain the range is replaced by one over the hull of both (a rank's Approx and Exact shards differ: equal
     // rows against equal area of the triangle); a hull of three quarters of the rows or more is not worth a panel
     if (h->KinvRows && !(h->kr0 <= row0 && row1 <= h->kr1)) { row0 = std::min(row0, h->kr0); row1 = std::max(row1, h->kr1); }
-    if (!h->Kinv && 4 * (row1 - row0) < 3 * np && panel_env && h->tri.ready() && row1 > row0) {
+    if (!h->Kinv && 4 * (row1 - row0) < 3 * np && h->tri.ready() && row1 > row0) {
         if (!(h->KinvRows && h->kr0 <= row0 && row1 <= h->kr1)) {
             hipStream_t s = h->stream;
             if (h->KinvRows) { GPX_HIP(hipStreamSynchronize(s)); dfree(h->KinvRows); h->KinvRows = nullptr; }
@@ -1377,6 +1376,99 @@ extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigm
     NEED_KERNEL(h, "gpx_exact_mean");
     if (!u || !Sigma || !mean) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     return exact_common(h, u, Sigma, false, mean, nullptr);
+}
+
+// ---- a14 for ANY operator.  The reference's UncertaintyPropagationExact talks to the GP only through _get_beta, _get_W_inv,
+// _inv_cov_matrix, _covariance and x (skgpuppy/UncertaintyPropagation.py:269-290, :323-379): with a Covariance subclass of its own
+// cov_matrix_ij / __call__ it runs and returns numbers -- Girard's correction factors built from theta[2:2+d], applied to the
+// operator's own C(u, x_i).  Here: C_ux [n] and cuu = cov(u, u) from the caller (the operator's scalar kernel on the host, N calls as in
+// the reference), x [n, d] and w [d] (the diagonal of _get_W_inv) handle-free, K^-1 and beta from the handle (gpx_fit_matrix or
+// gpx_fit) -- or, with h == NULL, explicit Kinv [n, n] and beta [n] (the reference's Kinv attribute, e.g. of an SPGP model); the
+// N and N^2 sums run in the kernels of the built-in path.  mean WITHOUT meant.
+__global__ __launch_bounds__(256) void mean_lower_kernel(double *A, long ld, long n)
+{
+    const long i = blockIdx.x;
+    for (long j = threadIdx.x; j < i; j += 256) A[i * ld + j] = 0.5 * (A[i * ld + j] + A[j * ld + i]);
+}
+
+extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d,
+                                          const double *w, const double *C_ux, const double *u, const double *Sigma, double cuu,
+                                          double *mean, double *var)
+{
+    GPX_TRY(gpx_require_device());
+    if (h) GPX_HIP(hipSetDevice(h->device));
+    if (!x || !w || !C_ux || !u || !Sigma || n < 1 || d < 1 || d > GPX_MAX_D || (!h && (!Kinv || !beta)) || (h && h->n != n)) {
+        gpx_set_error("gpx_propagate_exact_matrix: bad arguments (n=%ld d=%d%s)", (long)n, d, (h && h->n != n) ? ": the handle holds another n" : "");
+        return GPX_ERR_BAD_ARG;
+    }
+    for (int k = 0; k < d; ++k)
+        if (!(w[k] > 0.0) || !isfinite(w[k])) { gpx_set_error("gpx_propagate_exact_matrix: w[%d]=%g", k, w[k]); return GPX_ERR_BAD_ARG; }
+    const int64_t np = round_up(n, TILE);
+    hipStream_t s = h ? h->stream : nullptr;
+    const double *kbase = nullptr, *bdev = nullptr;
+    if (h) { GPX_TRY(ensure_kinv(h)); kbase = h->Kinv; bdev = h->alpha; }
+    // constants (UncertaintyPropagation.py:247-257, :292-303) exactly as exact_common builds them
+    std::vector<double> A((size_t)d * d), Ai((size_t)d * d), Ls((size_t)d * d), dd(d);
+    double nc1 = 1.0, nc2 = 1.0;
+    for (int k = 0; k < d; ++k) {
+        const double wk = w[k], sk = Sigma[k * d + k];
+        dd[k] = wk - wk / (1.0 + wk * sk);
+        nc1 *= (1.0 + wk * sk);
+        nc2 *= (2.0 * wk * sk + 1.0);
+    }
+    nc1 = 1.0 / sqrt(nc1);
+    nc2 = 1.0 / sqrt(nc2);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) A[(size_t)i * d + j] = Sigma[i * d + j] + (i == j ? 0.5 / w[i] : 0.0);
+    if (small_inverse(A.data(), d, Ai.data())) { gpx_set_error("W/2 + Sigma is singular"); return GPX_ERR_BAD_ARG; }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            const double lij = (i == j ? 2.0 * w[i] : 0.0) - Ai[(size_t)i * d + j];
+            const double lji = (i == j ? 2.0 * w[i] : 0.0) - Ai[(size_t)j * d + i];
+            Ls[(size_t)i * d + j] = 0.5 * (lij + lji);
+        }
+    double *buf = nullptr, *Kd = nullptr, *Kp = nullptr;
+    const int64_t need = (2 * (int64_t)d + 6) * np + n * (int64_t)d + (int64_t)d * d + 2 * d + 8;
+    GPX_TRY(dalloc(&buf, need));
+    double *aT = buf, *bT = aT + (int64_t)d * np, *e = bT + (int64_t)d * np, *F = e + np, *lm = F + np, *partial = lm + np;
+    double *Cd = partial + np, *bpad = Cd + np, *xd = bpad + np, *Lsd = xd + n * (int64_t)d, *ddd = Lsd + (int64_t)d * d, *ud = ddd + d, *outd = ud + d;
+    double o[2] = {0, 0};
+    int rc = 0;
+    hipError_t er = hipSuccess;
+    do {
+        if ((er = hipMemcpyAsync(Lsd, Ls.data(), sizeof(double) * d * d, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((er = hipMemcpyAsync(ddd, dd.data(), sizeof(double) * d, hipMemcpyHostToDevice, s)) != hipSuccess) break;
+        if ((er = hipMemcpyAsync(ud, u, sizeof(double) * d, hipMemcpyDefault, s)) != hipSuccess) break;
+        if ((er = hipMemcpyAsync(xd, x, sizeof(double) * n * d, hipMemcpyDefault, s)) != hipSuccess) break;
+        if ((er = hipMemcpyAsync(Cd, C_ux, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
+        if (!h) {
+            // explicit K^-1 / beta: zero-padded beta, K^-1 padded to the tile grid (the padding never enters: F = 0 there)
+            if ((rc = dalloc(&Kd, n * n)) || (rc = dalloc(&Kp, np * np))) break;
+            if ((er = hipMemcpyAsync(Kd, Kinv, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
+            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)np), dim3(256), 0, s, (const double *)Kd, (long)n, Kp, (long)np, 0.0);
+            // the pair kernel visits j <= i only (weight 2) where the reference sums both triangles: the lower triangle of a supplied
+            // K^-1 becomes the mean of both (a Woodbury-built inverse is symmetric to rounding only)
+            hipLaunchKernelGGL(mean_lower_kernel, dim3((unsigned)n), dim3(256), 0, s, Kp, (long)np, (long)n);
+            if ((er = hipMemsetAsync(bpad, 0, sizeof(double) * np, s)) != hipSuccess) break;
+            if ((er = hipMemcpyAsync(bpad, beta, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
+            kbase = Kp; bdev = bpad;
+        }
+        if ((rc = launch_exact_build_generic(xd, n, np, d, ud, Lsd, ddd, Cd, nc1, aT, bT, e, F, lm, s))) break;
+        std::vector<std::pair<const double *, const double *>> pr;
+        pr.push_back({bdev, lm});
+        if ((rc = launch_dot_pairs(pr, np, outd, s))) break;
+        if ((rc = launch_exact_sum(kbase, np, np, d, bdev, aT, bT, e, F, partial, outd + 1, s, h ? &h->prof : nullptr))) break;
+        if ((er = hipMemcpyAsync(o, outd, sizeof(double) * 2, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+    } while (0);
+    const hipError_t es = hipStreamSynchronize(s);
+    dfree(buf);
+    if (Kd) dfree(Kd);
+    if (Kp) dfree(Kp);
+    if (rc) return rc;
+    if (er != hipSuccess || es != hipSuccess) { gpx_set_error("gpx_propagate_exact_matrix: %s", hipGetErrorString(er != hipSuccess ? er : es)); return GPX_ERR_HIP; }
+    if (mean) *mean = o[0];
+    if (var) *var = cuu - nc2 * o[1] - o[0] * o[0];   // UncertaintyPropagation.py:377
+    return 0;
 }
 
 // ---- a4 with a caller-supplied matrix: Covariance.inv_cov_matrix(x, theta, cov_matrix=K) = inv(K)

@@ -169,7 +169,7 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                    hipStream_t s, Profiler *prof, int ktrim = 0, int tri = 0, int small_tiles = 0);
 // narrow update + bulk SYRK of a panel as ONE trapezoid launch that counts its finished narrow tiles in *sig_dev (gemm.hip)
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
-                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof);
+                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof, int *sigsq_dev = nullptr);
 // batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
 // tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
 enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3, GEMM_TRI_B_LOWER_PAIRED = 4 /* internal */,

@@ -358,7 +358,7 @@ __device__ __noinline__ int run_bulk(const DflowParams &p, const int *tab, int i
     const unsigned long long tb0 = STAMP(p);
     int v = 0;
     if (threadIdx.x < 64) v = look_issue(p, tab, req);
-    gemm_tile<4, 4>(tile_ptr(p, i, ka), p.ld, tile_ptr(p, j, ka), p.ld, tile_ptr(p, i, j), p.ld, 0, 0, 0, NBP * TILE, -1.0, 1.0, smem, p.nkeep != -3);
+    gemm_tile<4, 4>(tile_ptr(p, i, ka), p.ld, tile_ptr(p, j, ka), p.ld, tile_ptr(p, i, j), p.ld, 0, 0, 0, NBP * TILE, -1.0, 1.0, smem, true);
     const unsigned long long tb1 = STAMP(p);
     publish_add(st_ver(p, i, j), 8);
     if (threadIdx.x == 0) {
@@ -467,15 +467,12 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
     __shared__ int s_res, s_val, s_bad;
     const int t = threadIdx.x;
 
-    // (diagnostic GPX_DFLOW_BULKONLY: only the BULK tiles of panel 0, operands taken as they are -- the persistent loop's own tile rate)
-    const bool bulk_only = p.nside == -7;
     // ---- role LEAF ----------------------------------------------------------------------------------------------------
     if (blockIdx.x == 0) {
         if (t == 0) {
             const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
             st_agent(p.st + ST_LEAFCU, 1 + (int)(((xcc & 0xf) << 8) | ((hw >> 8) & 0xff)));
         }
-        if (bulk_only) return;
         for (int k = 0; k < p.leaf_steps; ++k) {
             const int q = k / NBP;
             Deps d;
@@ -502,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
         int lc = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while ((lc = ld_agent(p.st + ST_LEAFCU)) == 0 && __builtin_amdgcn_s_memrealtime() - t0 < 100000ull) __builtin_amdgcn_s_sleep(2);   // <= 1 ms
-        const bool side = !bulk_only && (p.side_first > 0 ? (int)blockIdx.x <= p.side_first : (int)((hw >> 8) & (unsigned)p.side_mask) == p.side_val);
+        const bool side = (p.side_first > 0 ? (int)blockIdx.x <= p.side_first : (int)((hw >> 8) & (unsigned)p.side_mask) == p.side_val);
         // ticket: -1 the leaf's mate; side workers count themselves (the chain queue needs at least one: see the launch function)
         s_val = (lc == me) ? -1 : (side ? (1 << 20) + add_agent(p.st + ST_SIDES, 1) : add_agent(p.st + ST_TICKETS, 1));
         s_bad = (int)(xcc & 7);
@@ -669,7 +666,6 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
             if (j != i) for (int u = 0; u < 4; ++u) d.add(st_prog(p, j, u), B1);
             d.add(st_ver(p, i, j), 8 * q);
             const unsigned long long tl1 = STAMP(p);
-            if (bulk_only) { d.n = 0; if (q > 0) return; }
             const int r = wait_deps(p, d, false, &s_res, &hand_t0);   // one look; the time limit since the claim is applied inside, uniformly
             if (r < 0) return;
             if (r == 1) {
@@ -691,7 +687,6 @@ __global__ __launch_bounds__(256, 2) void chol_dataflow_kernel(const DflowParams
             }
             continue;
         }
-        if (bulk_only) return;
         // nothing in hand and no tiles left: the queues' remainder is served by the first nkeep workers (plus the former side workers)
         if (pend_sq < 0 && pend_col < 0 && (live == 0 || (ticket < (1 << 20) && ticket >= p.nkeep))) return;
         // safety net: should no workgroup have landed on a designated CU (another chip layout), the first idle workers take the chain
@@ -835,9 +830,7 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
     p.gate = first_rows > 0 ? gate : nullptr;
     if (first_rows <= 0) extra = 0;
     p.limit = limit_ticks;
-    static const int nside = getenv("GPX_DFLOW_BULKONLY") ? -7 : 0;
-    static const int nkeep = [] { const char *e = getenv("GPX_DFLOW_KEEP"); return e ? atoi(e) : 192; }();
-    p.nside = nside; p.nkeep = getenv("GPX_DFLOW_PLAINSTORE") ? -3 : nkeep;   // (diagnostic: BULK tiles stored with plain stores -- timing only, not coherent)
+    p.nside = 0; p.nkeep = 192;   // workers kept for the queues' remainder once the trailing update has no tiles left
     static const int ncu = [] {
         int dev = 0, n = 256;
         hipDeviceProp_t prop;
@@ -845,10 +838,7 @@ int launch_chol_dataflow(double *L, int64_t ld, int64_t nb, int64_t c0, double *
         return n;
     }();
     static const int wg_env = [] { const char *e = getenv("GPX_DFLOW_WGS"); return e ? atoi(e) : 0; }();
-    // owning the tail only (c0 > 0) the kernel has little trailing-update work: it leaves a third of the chip's places to the caller's
-    // ride-along kernels that run beside it (chol.hip); the whole factorisation takes every place
-    static const int tail_wgs = [] { const char *e = getenv("GPX_DFLOW_TAIL_WGS"); return e ? atoi(e) : 0; }();
-    const int grid = wg_env > 0 ? wg_env : (c0 > 0 && tail_wgs > 0 ? tail_wgs : 2 * ncu);
+    const int grid = wg_env > 0 ? wg_env : 2 * ncu;
     p.trace = nullptr;
     p.trace_cap = 0;
     static const char *trace_path = getenv("GPX_DFLOW_TRACE");   // debug: per-task timeline -> file (the launch then blocks)

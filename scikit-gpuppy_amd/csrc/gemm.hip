@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 // XCD x (workgroups with blockIdx & 7 == x) takes the narrow 8 x off groups g = x, x + 8, .. (8 tile rows each: 64 tiles that share
 // 8 A and `off` B row panels through that XCD's L2), then its contiguous chunk of the triangle in the grouped order of lower_tile.
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
-                                                                        int K, double alpha, double beta, int off, int nt, int *sig)
+                                                                        int K, double alpha, double beta, int off, int nt, int *sig, int *sigsq)
 {
     __shared__ __attribute__((aligned(1024))) double smem[2 * 256 * 16];
     // 224 registers like the plain bulk kernel (the compiler gets by with 208 here): a wave of this kernel must NOT fit into the 216
@@ -128,14 +128,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const d
         lower_tile(start + idx - mine, 0, nt, by, bx);
         bx += off;
     }
-    const bool publish = narrow && sig;
+    // the triangle's first 8 tile rows are the NEXT diagonal square: counted in *sigsq, so that the square's own update (and the chain
+    // behind it, chol.hip) starts on its stream while this launch is still running
+    const bool square = !narrow && sigsq && by < 8;
+    const bool publish = (narrow && sig) || square;
     gemm_tile<4, 4>(A, lda, B, ldb, C, ldc, bx, by, 0, K, alpha, beta, smem, publish);
     if (publish) {
-        // The narrow tile went out as write-through (sc1) stores: every storing wave drains them, the workgroup meets, one lane
+        // The tile went out as write-through (sc1) stores: every storing wave drains them, the workgroup meets, one lane
         // counts the tile -- no write-back of the XCD's whole L2 (release fence) underneath the running bulk tiles.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(sig + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one counter per tile column
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(square ? sigsq : sig + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one counter per tile column
     }
 }
 
@@ -161,7 +164,7 @@ int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_
 }
 
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
-                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof)
+                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof, int *sigsq_dev)
 {
     if (M % TILE || off_cols % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0) {
         gpx_set_error("launch_syrk_trap_signal: shape/alignment not supported");
@@ -176,7 +179,7 @@ int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64
     }
     ProfScope ps(prof, s, GPX_K_GEMM, (double)nwg * 2.0 * TILE * TILE * (double)K, 1);
     hipLaunchKernelGGL(gemm_nt_f64_trap_signal_kernel, dim3((unsigned)nwg), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta,
-                       (int)off, (int)nt, sig_dev);
+                       (int)off, (int)nt, sig_dev, sigsq_dev);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -455,5 +458,5 @@ extern "C" int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, in
 extern "C" int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols,
                                  int64_t K, double alpha, double beta, int *count_dev, void *stream)
 {
-    return launch_syrk_trap_signal(A, lda, B, ldb, C, ldc, M, off_cols, K, alpha, beta, count_dev, (hipStream_t)stream, nullptr);
+    return launch_syrk_trap_signal(A, lda, B, ldb, C, ldc, M, off_cols, K, alpha, beta, count_dev, (hipStream_t)stream, nullptr, nullptr);
 }

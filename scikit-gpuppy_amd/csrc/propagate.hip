@@ -489,6 +489,49 @@ int launch_cjh(const double *x, int64_t n, int d, const double *u_dev, const dou
     return 0;
 }
 
+// The same per-row quantities for ANY operator (gpx_propagate_exact_matrix): C_i = cov(u, x_i) comes from the caller -- the operator's own
+// scalar kernel, as in the reference (UncertaintyPropagation.py:269-276, :339-343) --, so nothing of the built-in kernel is folded
+// into the exponent: F_i = C_i, e_i = a_i^T Lambda^-1 a_i / 8, l_i = C_i nc1 exp(a_i^T Delta^-1 a_i / 2)   (:257-266, :292-321)
+__global__ __launch_bounds__(256) void exact_build_generic_kernel(const double *__restrict__ x, long n, long npad, int d,
+                                                                 const double *__restrict__ u, const double *__restrict__ Ls,
+                                                                 const double *__restrict__ dinv_diag, const double *__restrict__ C, double nc1,
+                                                                 double *__restrict__ aT, double *__restrict__ bT, double *__restrict__ e,
+                                                                 double *__restrict__ F, double *__restrict__ lm)
+{
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npad) return;
+    if (i >= n) {
+        for (int k = 0; k < d; ++k) { aT[(long)k * npad + i] = 0.0; bT[(long)k * npad + i] = 0.0; }
+        e[i] = 0.0; F[i] = 0.0; lm[i] = 0.0;
+        return;
+    }
+    double qd = 0.0, ql = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const double ak = u[k] - x[i * d + k];
+        aT[(long)k * npad + i] = ak;
+        qd = fma(dinv_diag[k] * ak, ak, qd);
+    }
+    for (int k = 0; k < d; ++k) {
+        double row = 0.0;
+        for (int b = 0; b < d; ++b) row = fma(Ls[k * d + b], u[b] - x[i * d + b], row);
+        bT[(long)k * npad + i] = 0.25 * row;
+        ql = fma(u[k] - x[i * d + k], row, ql);
+    }
+    e[i] = 0.125 * ql;
+    F[i] = C[i];
+    lm[i] = C[i] * nc1 * exp(0.5 * qd);
+}
+
+int launch_exact_build_generic(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *Ls_dev,
+                               const double *dinv_diag_dev, const double *C_dev, double nc1, double *aT, double *bT, double *e, double *F,
+                               double *lm, hipStream_t s)
+{
+    hipLaunchKernelGGL(exact_build_generic_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, x, (long)n, (long)npad, d, u_dev,
+                       Ls_dev, dinv_diag_dev, C_dev, nc1, aT, bT, e, F, lm);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_exact_build(const double *x, int64_t n, int64_t npad, int d, const double *u_dev, const double *w_dev,
                        const double *Ls_dev, const double *dinv_diag_dev, double v, double vt, double nc1, double *aT,
                        double *bT, double *e, double *F, double *lm, hipStream_t s)

@@ -252,16 +252,37 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
             self._prepare_C_corr(len(u))
             self._prepare_C_corr2(len(u))
 
-    def _need_builtin(self):
-        if self.gp._route() != "gaussian":
-            raise NotImplementedError("UncertaintyPropagationExact is Girard's closed form for the ARD squared-exponential kernel: it needs "
-                                      "a GaussianProcess on the built-in GaussianCovariance (UncertaintyPropagationApprox serves any operator "
-                                      "with get_Jacobian / get_Hessian)")
+    def _generic_moments(self, u, Sigma_x, C_ux, want_var):
+        """Any operator but the fused built-in kernel (a from-scratch Covariance, a subclass that overrides a matrix builder, SPGP):
+        the reference's class talks to the GP only through _get_beta / _get_W_inv / _inv_cov_matrix / _covariance / x
+        (UncertaintyPropagation.py:269-290, :323-379), so it returns numbers for such a GP -- Girard's correction factors built from
+        theta[2:2+d], applied to the operator's own C(u, x_i).  C_ux comes from the operator's scalar kernel on the host (N calls, as
+        in the reference), the N and N^2 sums run on the device over the model's K^-1 (gpx_propagate_exact_matrix)."""
+        gp = self.gp
+        uu, S = _u_sigma(gp, u, Sigma_x)
+        x = _gpx.f64(gp.x)
+        if C_ux is None:
+            C_ux = np.array([gp._covariance(u, gp.x[i]) for i in range(gp.n)])
+        C = _gpx.f64(C_ux).reshape(gp.n)
+        w = _gpx.f64(np.diag(self.Winv))
+        cuu = float(gp._covariance(u, u)) if want_var else 0.0
+        mean, var = ctypes.c_double(), ctypes.c_double()
+        if gp._route() == "generic":
+            st = _gpx.lib.gpx_propagate_exact_matrix(gp._dev().handle, None, None, _gpx.ptr(x), gp.n, gp.d, _gpx.ptr(w), _gpx.ptr(C),
+                                                     _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), ctypes.byref(var))
+        else:
+            # (SPGP: the model's dense K^-1 -- what the reference's class reads through _inv_cov_matrix -- and beta = Kinv t)
+            Kinv, beta = _gpx.f64(gp._inv_cov_matrix()), _gpx.f64(gp._get_beta())
+            st = _gpx.lib.gpx_propagate_exact_matrix(None, _gpx.ptr(Kinv), _gpx.ptr(beta), _gpx.ptr(x), gp.n, gp.d, _gpx.ptr(w), _gpx.ptr(C),
+                                                     _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), ctypes.byref(var))
+        _gpx.check(st, "gpx_propagate_exact_matrix")
+        return mean.value, var.value
 
     def propagate_mean(self, u, Sigma_x, C_ux=None):
-        # C_ux is accepted for signature parity (UncertaintyPropagation.py:269); it is rebuilt on device
-        self._need_builtin()
+        # (UncertaintyPropagation.py:269-290); with the built-in kernel C_ux is rebuilt on the device (accepted for signature parity)
         self._set_constants(u, np.asarray(Sigma_x, dtype=float))
+        if self.gp._route() != "gaussian":
+            return np.float64(self._generic_moments(u, Sigma_x, C_ux, False)[0])
         uu, S = _u_sigma(self.gp, u, Sigma_x)
         out = ctypes.c_double()
         st = _gpx.lib.gpx_exact_mean(self.gp._dev().handle, _gpx.ptr(uu), _gpx.ptr(S), ctypes.byref(out))
@@ -270,9 +291,11 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
 
     def propagate_GA(self, u, Sigma_x):
         # (UncertaintyPropagation.py:323-379)
-        self._need_builtin()
         uu, S = _u_sigma(self.gp, u, Sigma_x)
         self._set_constants(uu, S)
+        if self.gp._route() != "gaussian":
+            mean, var = self._generic_moments(u, Sigma_x, None, True)
+            return np.float64(mean + self.gp._get_mean_t()), np.float64(var)
         mean, var = ctypes.c_double(), ctypes.c_double()
         st = _gpx.lib.gpx_propagate_exact(self.gp._dev().handle, _gpx.ptr(uu), _gpx.ptr(S), ctypes.byref(mean),
                                           ctypes.byref(var))

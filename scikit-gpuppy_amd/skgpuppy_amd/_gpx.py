@@ -65,6 +65,7 @@ SIGNATURES = {
     "gpx_propagate_exact": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_propagate_exact_rows": (_int, [_hp, _dp, _dp, _i64, _i64, _dp]),
     "gpx_exact_mean": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl)]),
+    "gpx_propagate_exact_matrix": (_int, [_hp, _dp, _dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
     "gpx_nll_grad": (_int, [_hp, _dp]),
     "gpx_spgp_fit": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _i64, ctypes.POINTER(_hp)]),

@@ -1,6 +1,6 @@
-"""The factorisation as one persistent dataflow launch (csrc/dflow.hip, gpx_dev_chol_dataflow; optional schedule of gpx_fit's Cholesky,
-GPX_DFLOW_FROM): the factor against numpy on ragged block counts, the trailing-part form, bit-identity of a fit that hands its last panels
-(or everything) to the kernel, and the stall protocol (an expired in-kernel wait aborts the launch and the fit repeats on the plain
+"""The factorisation as one persistent dataflow launch (csrc/dflow.hip, gpx_dev_chol_dataflow; the schedule of gpx_fit's Cholesky up to
+GPX_DFLOW_MAX_BLOCKS block rows, default none): the factor against numpy on ragged block counts, the trailing-part form, bit-identity of a
+fit that hands everything to the kernel, and the stall protocol (an expired in-kernel wait aborts the launch and the fit repeats on the plain
 schedule).  Replaces skgpuppy/Covariance.py:179 like the default schedule does."""
 import ctypes
 import os
@@ -88,13 +88,14 @@ print("JITTER %%g" %% gp._dev().jitter())
 
 
 def test_fit_with_dataflow_schedules_is_bit_identical(tmp_path):
-    """the fit's Cholesky with its last panels (GPX_DFLOW_FROM=-3), or all of them (0), handed to the dataflow kernel: the same tile
-    arithmetic in the same order as the launch-per-step schedule -> alpha agrees to the last bit; and the stall protocol: with a time
-    limit of 2 us every in-kernel wait expires, the launch aborts, the fit repeats on the plain schedule and still returns that alpha"""
+    """the fit's Cholesky handed to the dataflow kernel as a whole (GPX_DFLOW_MAX_BLOCKS above the matrix' 71 block rows; by default only
+    no fit goes there): the same tile arithmetic in the same order as the multi-stream schedule -> alpha agrees to the
+    last bit; and the stall protocol: with a time limit of 2 us every in-kernel wait expires, the launch aborts, the fit repeats on the
+    plain schedule and still returns that alpha"""
     code = _FIT_WORKER % {"pkg": os.path.join(ROOT, "scikit-gpuppy_amd")}
     betas = {}
-    variants = {"default": {"GPX_DFLOW_FROM": "off"}, "tail": {"GPX_DFLOW_FROM": "-3"}, "whole": {"GPX_DFLOW_FROM": "0"},
-                "stalled": {"GPX_DFLOW_FROM": "0", "GPX_WAIT_LIMIT_MS": "0.002", "GPX_DEBUG": "1"}}
+    variants = {"default": {"GPX_DFLOW_MAX_BLOCKS": "0"}, "whole": {"GPX_DFLOW_MAX_BLOCKS": "1000"},
+                "stalled": {"GPX_DFLOW_MAX_BLOCKS": "1000", "GPX_WAIT_LIMIT_MS": "0.002", "GPX_DEBUG": "1"}}
     for name, extra in variants.items():
         env = dict(os.environ)
         env.update(extra)
@@ -105,5 +106,5 @@ def test_fit_with_dataflow_schedules_is_bit_identical(tmp_path):
         if name == "stalled":
             assert "hand-off stalled: refit on the plain schedule" in r.stderr, r.stderr[-2000:]
         betas[name] = np.load(out)
-    for name in ("tail", "whole", "stalled"):
+    for name in ("whole", "stalled"):
         np.testing.assert_array_equal(betas[name], betas["default"])
