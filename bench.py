@@ -290,6 +290,42 @@ def spgp_section(n=262144, m=2048, d=8, queries=16384, reps=2):
             "mean_abs_residual": float(np.abs(mu - np.sin(0.3 * xs.sum(1))).mean())}
 
 
+def workload_point(lib, _gpx, name, warm, reps):
+    """Another BASELINE.json configuration on the same GPU, outside the timed region (the driver's record then holds a throughput
+    figure for every single-GPU configuration): fit + estimate_many through the C-ABI on device-resident inputs, like the headline
+    step; best of `reps` after `warm` warm-ups."""
+    wl = WORKLOADS[name]
+    N, d, M = wl["N"], wl["d"], wl["M"]
+    x, t, xs, theta = recipe(N, d, M)
+    dev = torch.device("cuda:0")
+    xd, td, xsd = torch.as_tensor(x).to(dev), torch.as_tensor(t - t.mean()).to(dev), torch.as_tensor(xs).to(dev)
+    mean_d = torch.empty(M, dtype=torch.float64, device=dev)
+    var_d = torch.empty(M, dtype=torch.float64, device=dev)
+    th = np.ascontiguousarray(theta)
+    vp = lambda tt: ctypes.c_void_p(tt.data_ptr())  # noqa: E731
+    best = None
+    for r in range(warm + reps):
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "gpx_fit")
+        b = time.perf_counter()
+        _gpx.check(lib.gpx_predict(h, vp(xsd), M, vp(mean_d), vp(var_d)), "gpx_predict")
+        torch.cuda.synchronize()
+        c = time.perf_counter()
+        lib.gpx_free(h)
+        if r >= warm and (best is None or c - a < best[0]):
+            best = (c - a, b - a, c - b)
+    finite = bool(torch.isfinite(mean_d).all().item() and torch.isfinite(var_d).all().item() and (var_d > 0).all().item())
+    del xd, td, xsd, mean_d, var_d
+    flops = N ** 3 / 3.0 + float(N) * N * M
+    return {"workload": "%s: N=%d d=%d M=%d fit + estimate_many, device-resident inputs" % (name.upper(), N, d, M),
+            "warmup": warm, "best_of": reps, "fit_ms": best[1] * 1e3, "estimate_many_ms": best[2] * 1e3, "ms_per_step": best[0] * 1e3,
+            "pts_per_s": (N + M) / best[0], "algorithmic_flops": flops, "tflops": flops / best[0] / 1e12,
+            "frac_of_peak": flops / best[0] / 1e12 / FP64_MFMA_PEAK_TFLOPS, "fit_frac_of_peak": N ** 3 / 3.0 / best[1] / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "outputs_finite_and_var_positive": finite}
+
+
 def propagate_parity(cb, d):
     """Config C3's second half against the oracle at the benchmark size: propagate_GA (Approx and Exact, u = 5 1_d, Sigma = 0.01 I)
     on a GPU fit of the oracle's inputs against oracle.approx_propagate / exact_propagate on the oracle's own K^-1 (serial C
@@ -476,6 +512,11 @@ def run_single(args):
             _gpx.lib.gpx_pool_trim()
             out["spgp_c5_f3"] = spgp_section()
             _gpx.lib.gpx_pool_trim()
+            # the other single-GPU configurations of BASELINE.json, so that every one of them has a driver-witnessed figure
+            out["c2"] = workload_point(lib, _gpx, "c2", warm=3, reps=10)
+            _gpx.lib.gpx_pool_trim()
+            out["c4_one_gpu"] = workload_point(lib, _gpx, "c4", warm=1, reps=2)   # the one-GPU point of the N = 65536 scaling curve
+            _gpx.lib.gpx_pool_trim()
     if not args.no_cpu:
         cb = cpu_baseline(N, d, M, budget_s=args.cpu_budget)
         Ns, Ms, tf, tp = cb["N"], cb["M"], cb["fit_s"], cb["predict_s"]
@@ -534,7 +575,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=240.0, help="seconds the CPU baseline may take (full workload if it fits)")
     ap.add_argument("--no-python-api", action="store_true", help="skip the second figure through the Python classes")
     ap.add_argument("--no-propagate", action="store_true", help="skip the (untimed) propagate_GA section and its parity check against the oracle")
-    ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) likelihood (f1) and SPGP config-5 (f3) figures")
+    ap.add_argument("--no-extras", action="store_true", help="skip the (untimed) likelihood (f1), SPGP config-5 (f3), C2 and one-GPU C4 figures")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("GPX_BENCH_SHARDED"):

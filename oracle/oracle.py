@@ -463,6 +463,36 @@ def exact_propagate(gp, u, Sigma):
     return mu + gp.meant, (v + vt) - s - mu ** 2
 
 
+def exact_propagate_operator(gp, covariance, u, Sigma, C=None, mean_only=False):
+    """UncertaintyPropagationExact on ANY GP object (UncertaintyPropagation.py:269-290, :323-379): the class reads the GP only through
+    _get_beta (gp.beta()), _get_W_inv (exp(theta_min[2:2+d]) -- whatever those entries mean to the operator), _inv_cov_matrix (gp.Kinv),
+    x, _get_mean_t and _covariance = covariance(u, x_i) (the operator's scalar kernel).  Returns (mean + meant, variance), or the mean
+    WITHOUT meant for mean_only (propagate_mean, which also accepts a caller's C_ux)."""
+    x = _c(np.asarray(gp.x, dtype=float))
+    u = _c(u)
+    Sigma = np.asarray(Sigma, dtype=float)
+    n, d = x.shape
+    w = np.exp(np.asarray(gp.theta_min, dtype=float)[2:2 + d])
+    Winv = np.diag(w)
+    if C is None:
+        C = np.array([float(np.ravel(covariance(u, gp.x[i]))[0]) for i in range(n)])
+    C = _c(C)
+    Dinv = Winv - np.diag(w / (1.0 + w * np.diag(Sigma)))
+    nc1 = 1.0 / np.sqrt(np.linalg.det(np.eye(d) + Winv * Sigma))
+    beta = _c(gp.beta() if callable(getattr(gp, "beta", None)) else np.dot(gp.Kinv, gp.t))
+    mu = 0.0
+    for i in range(n):
+        a = u - x[i]
+        mu += beta[i] * C[i] * nc1 * np.exp(0.5 * np.dot(a, np.dot(Dinv, a)))
+    if mean_only:
+        return mu
+    Linv = _c(2.0 * Winv - inv(0.5 * np.diag(1.0 / w) + Sigma))
+    nc2 = 1.0 / np.sqrt(np.linalg.det(2.0 * Winv * Sigma + np.eye(d)))
+    s_ = _loops().orc_exact_sum(_p(_c(gp.Kinv)), _p(beta), _p(C), _p(x), _p(u), _p(Linv), float(nc2), n, d)
+    cuu = float(np.ravel(covariance(u, u))[0])
+    return mu + gp.meant, cuu - s_ - mu ** 2
+
+
 # --------------------------------------------------------------------------------------------
 # "next" row f3: Snelson sparse pseudo-input covariance  (reference: Covariance.py:692-1019)
 # theta = (log v, log vt, log w_1..d, pseudo-inputs flattened row-major)
@@ -485,6 +515,16 @@ def spgp_cov_matrix_ij(xi, xj, theta, m):
     Zi = solve_triangular(_spgp_lm(tg, xm), gram_ij(xm, xi, tg), lower=True)
     Zj = solve_triangular(_spgp_lm(tg, xm), gram_ij(xm, xj, tg), lower=True)
     return np.dot(Zi.T, Zj)
+
+
+def spgp_scalar_cov(xi, xj, theta, m):
+    """SPGPCovariance.__call__  (Covariance.py:709-728): the full Gaussian kernel (incl. its +vt quirk) when xi == xj elementwise,
+    otherwise the subset-of-regressors value k_iM (K_M + 1e-5 I)^-1 k_Mj."""
+    xi, xj = np.asarray(xi, dtype=float), np.asarray(xj, dtype=float)
+    tg, _xm = spgp_split(theta, len(xi), m)
+    if (xi == xj).all():
+        return scalar_cov(xi, xj, tg)
+    return float(spgp_cov_matrix_ij(xi[None, :], xj[None, :], theta, m)[0, 0])
 
 
 def spgp_lambda(x, theta, m):

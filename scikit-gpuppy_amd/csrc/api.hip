@@ -721,11 +721,15 @@ static int predict_common(gpx_handle *h, const double *xs, const double *kv, con
     const int64_t chunk = std::min<int64_t>(round_up(m, TILE), cap);
     GPX_TRY(ensure_Z(h, chunk));
     // the triangular solve runs out of place against the inverted diagonal squares (tsolve.hip): second slab-major buffer
-    double *xq = nullptr, *xqw = nullptr, *mv = nullptr, *Zs = nullptr, *kd = nullptr;
+    double *xq = nullptr, *xqw = nullptr, *mv = nullptr, *Zs = nullptr, *kd = nullptr, *part = nullptr;
     GPX_TRY(dalloc(&Zs, chunk * h->npad));
     int rc = 0;
-    if ((rc = dalloc(&xq, chunk * std::max(d, 1))) || (rc = dalloc(&xqw, chunk * std::max(d, 1))) || (rc = dalloc(&mv, 2 * chunk)) || (rc = dalloc(&kd, chunk))) {
-        dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw); if (mv) dfree(mv);
+    // the row sums |z|^2 and z.y ride in the epilogue of each slab's last product (tsolve.hip): per row one partial pair per 64 columns
+    const int64_t nslots = h->npad / 64;
+    const bool fused = chunk >= 3072;
+    if ((rc = dalloc(&xq, chunk * std::max(d, 1))) || (rc = dalloc(&xqw, chunk * std::max(d, 1))) || (rc = dalloc(&mv, 2 * chunk)) || (rc = dalloc(&kd, chunk)) ||
+        (fused && (rc = dalloc(&part, 2 * chunk * nslots)))) {
+        dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw); if (mv) dfree(mv); if (kd) dfree(kd);
         return rc;
     }
     for (int64_t m0 = 0; m0 < m && rc == 0; m0 += chunk) {
@@ -745,9 +749,17 @@ static int predict_common(gpx_handle *h, const double *xs, const double *kv, con
             if (e != hipSuccess) { gpx_set_error("copy kv / kdiag failed: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; break; }
         }
         // Z <- kv L^-T  : row m of Z is (L^-1 kv_m)^T
-        if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof))) break;
         // var = k_mm - |z|^2 (k_mm = v + vt for the built-in kernel: k includes vt, GaussianProcess.py:75,78) ; mean = z . y
-        if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof, xs ? nullptr : kd))) break;
+        if (fused && mp >= 3072) {
+            GemmReduce red;
+            red.y = h->y; red.p2 = part; red.py = part + chunk * nslots; red.nslots = nslots;
+            if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof, &red))) break;
+            ProfScope ps(&h->prof, s, GPX_K_REDUCE, 16.0 * (double)mc * (double)nslots);
+            if ((rc = launch_predict_finish(red.p2, red.py, nslots, mc, h->v + h->vt, mv, mv + chunk, s, xs ? nullptr : kd))) break;
+        } else {
+            if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof))) break;
+            if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof, xs ? nullptr : kd))) break;
+        }
         e = hipMemcpyAsync(mean_out + m0, mv, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipMemcpyAsync(var_out + m0, mv + chunk, sizeof(double) * mc, hipMemcpyDefault, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -759,6 +771,7 @@ static int predict_common(gpx_handle *h, const double *xs, const double *kv, con
     dfree(xqw);
     dfree(mv);
     dfree(kd);
+    if (part) dfree(part);
     return rc;
 }
 

@@ -10,7 +10,6 @@
 // block AND inverts its factor in one launch, both on MFMA out of LDS, so that every triangular solve against a
 // diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -498,7 +497,7 @@ static int blocker_stream_prio()
 void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top)
 {
     if (!s_pan) return;
-    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || (streams_run_concurrently(s_top, s) && streams_run_concurrently(s_top, s_pan)));
+    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
     if (!concurrent || reserve_cus() == 0) return;
     hipStream_t s_blk = stream_acquire(blocker_stream_prio());   // the cache hands the same stream to chol_factor's own acquire
     if (!s_blk) return;
@@ -507,10 +506,11 @@ void chol_probe_streams(hipStream_t s, hipStream_t s_pan, hipStream_t s_top)
 }
 
 // Fits of at most this many block rows (GPX_DFLOW_MAX_BLOCKS, default 0 = none) run as ONE launch of the persistent dataflow kernel
-// (dflow.hip) instead of the multi-stream schedule.  Measured at N = 4096 (32 block rows, round 5): 3.0 ms against 2.36 ms -- with four
-// square launches the multi-stream schedule already pays one launch per panel, and the whole-matrix kernel's workers poll queues in HBM
-// between tasks.  Callers without look-ahead streams (SPGP's M x M blocks, gpx_spd_inverse) use it up to 64 block rows: 1.0 ms
-// against 2.2 ms of dependent launches for a 2048 x 2048 block.
+// (dflow.hip) instead of the multi-stream schedule.  Measured at N = 4096 (32 block rows, round 5, profiles/r05_probe_c2_*): 3.0 ms
+// against 2.36 ms -- with four square launches the multi-stream schedule already pays one launch per panel, and the whole-matrix
+// kernel's workers poll queues in HBM between tasks: not the default at any size; tests/test_dataflow.py runs a fit through it.
+// Callers without look-ahead streams (SPGP's M x M blocks, gpx_spd_inverse) use the kernel up to 64 block rows (GPX_DFLOW_SMALL=0:
+// never): 1.0 ms against 2.2 ms of dependent launches for a 2048 x 2048 block.
 static int64_t dflow_max_blocks()
 {
     static const int64_t v = [] { const char *e = getenv("GPX_DFLOW_MAX_BLOCKS"); return e ? atol(e) : 0L; }();
@@ -521,37 +521,32 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 hipStream_t s_pan, Profiler *prof, hipStream_t s_top, const std::function<int()> *after_fork,
                 const std::function<int(int64_t, int64_t, bool, hipStream_t)> *panel_final)
 {
-    // (callers without look-ahead streams -- SPGP's M x M blocks, gpx_spd_inverse -- up to 64 block rows; a negative limit: never)
-    const int64_t df_limit = dflow_max_blocks() < 0 ? 0 : ((s_pan && s_top) ? dflow_max_blocks() : std::max<int64_t>(64, dflow_max_blocks()));
-    const bool whole_dflow = nblk > CHOL_NBP && nblk <= df_limit && !g_force_plain && chol_dataflow_supported(nblk);
-    if (nblk <= CHOL_NBP || s_pan == nullptr || s_top == nullptr || whole_dflow) {
+    if (nblk <= CHOL_NBP || s_pan == nullptr) {
         if (after_fork) GPX_TRY((*after_fork)());
-        // One panel, callers without look-ahead streams (SPGP's M x M blocks, gpx_spd_inverse: up to 64 block rows) and small fits: the
-        // whole matrix goes to the persistent dataflow kernel (dflow.hip) -- a 2048 x 2048 factorisation is a chain of 16 steps, 1.0 ms
-        // there against 2.2 ms of dependent launches.  Its in-kernel waits are bounded; one that expires sets the STALL word (info_dev[1]),
-        // which the fit answers with a refit on the plain schedule (api.hip) and the other callers report.
-        if (whole_dflow) {
+        // Callers without look-ahead streams (SPGP's M x M blocks, gpx_spd_inverse): between 9 and 64 block rows the whole matrix goes to
+        // the persistent dataflow kernel (dflow.hip) -- a 2048 x 2048 factorisation is a chain of 16 steps, 1.0 ms there against 2.2 ms
+        // of dependent launches.  Its in-kernel waits are bounded; one that expires (it never has) is reported, not retried: the
+        // matrix is overwritten by then.  The call synchronises the stream (the kernel's state words are freed here).
+        static const int small_df = [] { const char *e = getenv("GPX_DFLOW_SMALL"); return e ? atoi(e) : 1; }();
+        if (nblk > CHOL_NBP && nblk <= 64 && small_df && !g_force_plain && chol_dataflow_supported(nblk)) {
             double *st = nullptr;
             GPX_TRY(dalloc(&st, (chol_dataflow_state_ints(nblk) + chol_dataflow_table_ints(nblk)) / 2 + 2));
             std::vector<int> tab;
             int st_host[2] = {0, 0};
             hipError_t e = hipMemsetAsync(info_dev + 1, 0, sizeof(int), s);
             int rc = e == hipSuccess ? launch_chol_dataflow(L, ld, nblk, 0, Dinv, diagL, info_dev, reinterpret_cast<int *>(st), tab, wait_limit_ticks(), s, 0, 0) : 0;
-            // the caller's work behind the factorisation (alpha) is queued before the host waits for the launch
-            if (e == hipSuccess && !rc && panel_final) rc = (*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true, nullptr);
             if (e == hipSuccess && !rc) e = hipMemcpyAsync(st_host, info_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, s);
-            const hipError_t e2 = hipStreamSynchronize(s);   // (the kernel's state words are freed here)
+            const hipError_t e2 = hipStreamSynchronize(s);
             dfree(st);
             GPX_TRY(rc);
             GPX_HIP(e);
             GPX_HIP(e2);
-            if (st_host[1] && !(s_pan && s_top)) {   // (the fit reads the stall word itself and repeats on the plain schedule: api.hip)
-                gpx_set_error("factorisation of a %ld-row block: an in-kernel hand-off timed out (GPX_WAIT_LIMIT_MS); GPX_DFLOW_MAX_BLOCKS=-1 selects the launch chain",
+            if (st_host[1]) {
+                gpx_set_error("factorisation of a %ld-row block: an in-kernel hand-off timed out (GPX_WAIT_LIMIT_MS); GPX_DFLOW_SMALL=0 selects the launch chain",
                               (long)(nblk * TILE));
                 return GPX_ERR_STATE;
             }
-            return 0;
-        }
+        } else
         GPX_TRY((nblk <= CHOL_NBP) ? chol_panel_factor(L, ld, nblk, 0, nblk, Dinv, diagL, info_dev, s, prof)
                                    : chol_rec(L, ld, 0, nblk, Dinv, diagL, info_dev, s, prof));
         if (panel_final) GPX_TRY((*panel_final)((nblk + CHOL_NBP - 1) / CHOL_NBP - 1, 0, true, nullptr));
@@ -562,36 +557,41 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     while (Bs.back() < nblk) Bs.push_back(std::min<int64_t>(nblk, Bs.back() + CHOL_NBP));
     const int64_t P = (int64_t)Bs.size() - 1;
     auto bnd = [&](int64_t p) { return Bs[std::min<int64_t>(p, P)]; };
-    // Three streams, two panels of look-ahead.  With T(p) = the trailing update with panel p (one trapezoid launch: the next panel's
-    // columns first, then the lower triangle of everything right of them), chain(p) = the factorisation of panel p's diagonal square,
-    // S(p) = the solves of the rows below that square, Q(p) = the update of square p + 1 with panel p's rows of that square:
-    //   main stream s      T(0) T(1) T(2) ...  back to back; T(p) waits for chain(p) and S(p) (events)
-    //   chain stream s_pan Q(p) chain(p+1) Q(p+1) chain(p+2) ...; Q(p) waits for S(p) (event) and for the tiles of square p + 1 in
-    //                      T(p-1) -- counted by that launch in a device word, so Q(p) and chain(p+1) run BESIDE T(p-1)
-    //   solve stream s_top S(p+1) column by column: column j waits for the narrow tiles of T(p)'s tile column j (counters) and for
-    //                      chain(p+1)'s step j (event) -- the chain ran beside T(p-1), so S(p+1) only follows T(p)'s first tiles
-    // Rounds 1-4 had Q(p) on the main stream between T(p-1) and T(p): the chain could not start before T(p-1) had ended, every panel
-    // paid the square update (30 us), two launch gaps and whatever S(p) still lacked as idle time of the main stream (1.3 ms per fit),
-    // and in the tail -- where the chains are the critical path -- each chain started a whole bulk launch late.
-    // (its column solves wait for kernels of other streams from another stream: needs streams that run side by side)
-    const bool concurrent = streams_run_concurrently(s_pan, s) && streams_run_concurrently(s_top, s) && streams_run_concurrently(s_top, s_pan);
-    // Square-kernel mode: the diagonal chain of a panel -- 8 x (leaf, in-square solve, rank-128 update) = 24 dependent launches -- is ONE
-    // small launch of the dataflow kernel on the panel's square (leaf + side workers, dflow.hip), and the column solves of the rows below
-    // wait for its step counter instead of for events.  Used where the chain is the critical path and the chip has empty CUs for it: the
-    // panels whose trailing update has fewer than GPX_SQK_TILES tiles left (default 1000: the last five panels at N = 16384) and the
-    // first panel (nothing but the Gram kernel's remainder runs beside it).  GPX_SQK_FROM = p forces it from panel p on (0: everywhere;
-    // -1: never).  The launch also solves the NEXT diagonal square's rows for its columns (COL tasks of 32 more workgroups, in step with
-    // the chain), so that Q follows the launch at once; the third stream's column solves keep the rows further down.
+    // the whole factorisation as one launch of the dataflow kernel (see dflow_max_blocks): pdf = 0, else pdf = P (never)
+    int64_t pdf = P;
+    if (!g_force_plain && nblk <= dflow_max_blocks() && chol_dataflow_supported(nblk)) pdf = 0;
+    double *dfl_state = nullptr;
+    std::vector<int> dfl_tab;
+    if (pdf < P) {
+        const int64_t nbr = nblk - bnd(pdf);
+        GPX_TRY(dalloc(&dfl_state, (chol_dataflow_state_ints(nbr) + chol_dataflow_table_ints(nbr)) / 2 + 2));
+    }
+    auto run_dataflow = [&](int64_t p_first) -> int {
+        GPX_TRY(launch_chol_dataflow(L, ld, nblk, bnd(p_first), Dinv, diagL, info_dev, reinterpret_cast<int *>(dfl_state), dfl_tab, wait_limit_ticks(), s, 0, 0));
+        if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true, nullptr));
+        return 0;
+    };
+    // (its column solves wait for the kernel's counters from another stream: needs streams that run side by side, like the trapezoid hand-off)
+    const bool concurrent_ok = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    // Square-kernel mode: the diagonal chain of a panel -- 8 x (leaf, in-square solve,
+    // rank-128 update) = 24 dependent launches -- is ONE small launch of the dataflow kernel on the panel's square (leaf + side workers,
+    // dflow.hip), and the column solves of the rows below wait for its step counter instead of for events.
+    // Used where the chain is the critical path and the chip has empty CUs for it: for the panels whose trailing update has fewer than
+    // GPX_SQK_TILES tiles left (default 1000: the last six panels at N = 16384), and -- GPX_SQK_FIRST, default on -- for the first panel
+    // (nothing but the Gram kernel's remainder runs beside it).  GPX_SQK_FROM = p forces it from panel p on (0: everywhere; -1: never).
     static const int64_t sqk_from = [] { const char *e = getenv("GPX_SQK_FROM"); return e ? atol(e) : (int64_t)-2; }();
     static const long sqk_tiles = [] { const char *e = getenv("GPX_SQK_TILES"); return e ? atol(e) : 1000L; }();
     static const int sqk_workers = [] { const char *e = getenv("GPX_SQK_WORKERS"); return e ? atoi(e) : 32; }();
-    constexpr int sqk_extra = 32;
-    const bool sqk_on = !g_force_plain && concurrent && sqk_from != -1 && chol_dataflow_supported(CHOL_NBP);
-    // State words: 1024 ints per panel (chol_dataflow_state_ints(16) = 928), zeroed on the MAIN stream in front of the factorisation's
-    // first event -- the column solves on s_top poll them, and a recycled buffer holds the previous fit's finished counters; the task
-    // tables of all square launches are uploaded once, behind the states.  The rows below a square reach its launch through another
-    // stream's update: gate word per panel, set behind that update.
+    const bool sqk_on = !g_force_plain && concurrent_ok && sqk_from != -1 && chol_dataflow_supported(CHOL_NBP);
+    // State words: 1024 ints per panel (chol_dataflow_state_ints(8) = 656), zeroed on the MAIN stream in front of the factorisation's first
+    // event -- the column solves on s_top poll them, and a recycled buffer holds the previous fit's finished counters; the task tables of
+    // a full square and of a shorter last one are uploaded once, behind the states.
+    // GPX_SQK_NEXT (default 1): the square launch also solves the NEXT diagonal square's rows for its columns (COL tasks of GPX_SQK_EXTRA
+    // more workgroups, in step with the chain), so that the update of the next square -- what the next chain waits for -- follows the
+    // launch at once instead of waiting for the column solves of ALL rows below on the third stream; those keep the rows further down,
+    // which only the trailing update needs.  The rows reach the launch through another stream's update: gate word per panel, set behind it.
     constexpr int64_t SQK_STATE = 1024, SQK_TAB = 256, SQK_GATE = 1008;
+    constexpr int sqk_extra = 32;
     double *sqk_buf = nullptr;
     std::vector<std::vector<int>> sqk_tabs((size_t)P);
     std::vector<int> sqk_tab_host;
@@ -599,12 +599,13 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     auto sqk_state = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + pp * SQK_STATE; };
     auto sqk_tab = [&](int64_t pp) { return reinterpret_cast<int *>(sqk_buf) + P * SQK_STATE + pp * SQK_TAB; };
     auto sqk_gate = [&](int64_t pp) { return sqk_state(pp) + SQK_GATE; };
-    auto sqk_below = [&](int64_t pp) -> int64_t { return bnd(pp + 2) - bnd(pp + 1); };   // block rows below panel pp's square that its launch solves as well
+    // block rows below panel pp's square that its square launch solves as well (the next square's)
+    auto sqk_below = [&](int64_t pp) -> int64_t { return s_top ? bnd(pp + 2) - bnd(pp + 1) : 0; };
     auto use_sqk = [&](int64_t pp) {
         if (!sqk_on || pp < 0 || pp >= P) return false;
         if (sqk_from >= 0) return pp >= sqk_from;
         if (pp == 0) return true;
-        const int64_t nrem = nblk - bnd(pp + 1);               // block rows below panel pp
+        const int64_t nrem = nblk - bnd(pp + 1);               // block rows below panel pp: the trailing update that runs beside its chain is panel pp - 1's
         return nrem * (nrem + 1) / 2 + nrem * CHOL_NBP < sqk_tiles;
     };
     // the chain of panel pp's square [Ba, Bb) as one launch on s_pan; its column solves (rows below, stream s_top) per finished step
@@ -636,23 +637,27 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     auto sqk_open_gate = [&](int64_t pp, hipStream_t on) {
         if (use_sqk(pp) && sqk_below(pp) > 0) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, on, sqk_gate(pp), 1);
     };
-    std::vector<hipEvent_t> ev_pf(P), ev_top(P + 1), ev_tu(P), ev_first(P), ev_sq(P), top_events;
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
     for (int64_t p = 0; p < P; ++p) {
         GPX_HIP(hipEventCreateWithFlags(&ev_pf[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_next[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_top[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_tu[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_first[p], hipEventDisableTiming));
-        GPX_HIP(hipEventCreateWithFlags(&ev_sq[p], hipEventDisableTiming));
     }
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
     // CU reservation (above) for the tail of the factorisation: flag and placement counter live behind the status word; the
-    // blockers run on a stream of their own (high priority: that class has its own hardware queues)
+    // blockers run on a stream of their own
+    // (the waiting kernel on the chain's stream, its release on the main stream: the order in which the fit first uses its streams --
+    // the runtime binds a stream to a hardware queue at its first launch, and another order was measured to cost 5 ms per fit)
+    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
     int nres = concurrent ? reserve_cus() : 0;
+    // (high priority: that class has its own hardware queues, which an application's ordinary streams do not crowd)
     const int blk_prio = blocker_stream_prio();
     hipStream_t s_blk = nres ? stream_acquire(blk_prio) : nullptr;
-    if (s_blk && !(streams_run_concurrently(s_blk, s) && streams_run_concurrently(s_blk, s_pan) && streams_run_concurrently(s_blk, s_top))) {
+    if (s_blk && !(streams_run_concurrently(s_blk, s) && streams_run_concurrently(s_blk, s_pan) && (!s_top || streams_run_concurrently(s_blk, s_top)))) {
         // the blockers would sit in front of launches their release depends on
         stream_release(s_blk, blk_prio);
         s_blk = nullptr;
@@ -660,15 +665,14 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     }
     int *stall = info_dev + 1, *stop_flag = info_dev + 2, *placed = info_dev + 3;   // info_dev: [0] potrf status, [1] stall, then these, then sig
     static const int trap_env = [] { const char *e = getenv("GPX_TRAP"); return e ? atoi(e) : 1; }();
-    const int trap_on = trap_env && concurrent && !g_force_plain;
+    const int trap_on = trap_env && concurrent;
     int *sig = info_dev + 4;                                   // CHOL_NBP counters per panel: finished narrow tiles of its trapezoid launch by tile column
-    int *sigsq = sig + P * CHOL_NBP;                           // one per panel: finished tiles of the NEXT diagonal square in its trapezoid launch
     bool reserved = false, released = false;
     hipEvent_t ev_blk = nullptr;
     auto release_blockers = [&](hipStream_t on) {
         if (reserved && !released) { hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, on, stop_flag, 1); released = true; }
     };
-    // queued on the main stream between two trailing updates: the blockers take CUs as the previous launch's last workgroups retire
+    // called where the main stream has just drained (it waits for panel p's chain): the blockers find an empty chip
     auto reserve_now = [&]() -> int {
         if (!s_blk || reserved) return 0;
         GPX_HIP(hipEventCreateWithFlags(&ev_blk, hipEventDisableTiming));
@@ -684,31 +688,36 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         reserved = true;
         return 0;
     };
-    auto count_wait = [&](hipStream_t on, const int *ctr, int want) -> int {
-        hipLaunchKernelGGL(wait_count_kernel, dim3(1), dim3(1), 0, on, ctr, want, wait_limit_ticks(), stall);
-        GPX_HIP(hipGetLastError());
-        return 0;
-    };
     auto run = [&]() -> int {
-        if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP + P), s));
+        // Per outer panel p the main stream runs, in order:
+        //   update of panel p+1's diagonal square (panel p's rows of that square are solved by then) -> event: the side
+        //   stream starts the next chain;  update of the remaining rows of panel p+1's columns;  bulk SYRK of everything
+        //   right of panel p+1
+        // the side stream runs the diagonal-square chain of panel p+1 (leaf kernels and tiny GEMMs, pure latency)
+        // underneath all of that, and the third stream solves ALL rows below panel p's square column by column alongside
+        // panel p's chain (TopPipe), so that neither a top slice nor a panel TRSM remains on the main stream.
+        if (pdf == 0) {   // the whole factorisation is the dataflow kernel's
+            if (after_fork) GPX_TRY((*after_fork)());
+            return run_dataflow(0);
+        }
+        if (trap_on) GPX_HIP(hipMemsetAsync(sig, 0, sizeof(int) * (size_t)(P * CHOL_NBP), s));
         GPX_TRY(sqk_prepare());
         sqk_open_gate(0, s);   // (the first panel's columns are complete when the factorisation is called)
         GPX_HIP(hipEventRecord(ev0, s));
         GPX_HIP(hipStreamWaitEvent(s_pan, ev0, 0));
         std::vector<TopPipe> tops(P + 1);
-        auto piped = [&](int64_t q) { return bnd(q + 1) < nblk; };
+        auto piped = [&](int64_t q) { return s_top && bnd(q + 1) < nblk; };
         for (int64_t q = 0; q < P; ++q) {
             tops[q].stream = piped(q) ? s_top : nullptr;
             tops[q].r0 = bnd(q + 1) + (use_sqk(q) ? sqk_below(q) : 0);   // (a square launch solves the next square's rows itself)
             tops[q].r1 = nblk;
             tops[q].events = &top_events;
-            tops[q].stall = stall;
         }
         if (piped(0)) GPX_HIP(hipStreamWaitEvent(s_top, ev0, 0));
-        // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued behind the first
-        // chain step, it runs underneath the first panel's diagonal chain
-        // (that step's leaf is NOT exclusive: the Gram kernel, released on the main stream at the same moment, usually wins the race for
-        // the places, and an exclusive leaf would then wait for the whole launch to drain)
+        // main-stream work of the caller that only the later panels need (the rest of the Gram matrix): queued now, it runs
+        // underneath the first panel's chain
+        // (the first step is queued ahead of that launch; its leaf is NOT exclusive: the Gram kernel, released on the main stream at
+        // the same moment, usually wins the race for the places, and an exclusive leaf would then wait for the whole launch to drain)
         if (use_sqk(0)) {
             GPX_TRY(sqk_launch(0, 0, bnd(1)));
             tops[0].sq_state = sqk_state(0);
@@ -718,81 +727,79 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             if (tops[0].stream && tops[0].r1 > tops[0].r0)
                 for (int64_t j = 0; j < bnd(1); ++j) GPX_TRY(top_column(L, ld, 0, j, Dinv, &tops[0], prof));
         } else {
-            GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 0));
-            if (after_fork) GPX_TRY((*after_fork)());
-            GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 1, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));   // nothing else fills the chip yet: every leaf finds an empty CU
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 0, 1, Dinv, diagL, info_dev, s_pan, prof, &tops[0], 0));
+        if (after_fork) GPX_TRY((*after_fork)());
+        GPX_TRY(chol_square_steps(L, ld, 0, bnd(1), 1, bnd(1), Dinv, diagL, info_dev, s_pan, prof, &tops[0], 2));   // nothing else fills the chip yet: every leaf finds an empty CU
         }
-        GPX_HIP(hipEventRecord(ev_sq[0], s));                   // the caller's Gram remainder holds the second square: Q(0) waits for it
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
-        bool sq_counted = false;                               // T(p-1) counts the tiles of square p + 1 in sigsq[p-1] (else: ev_sq[p])
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
+            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
             if (B1 >= nblk) {
-                GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of the last panel is factored
                 if (panel_final) GPX_TRY((*panel_final)(p, 0, true, nullptr));
                 break;
             }
-            const int64_t K = (B1 - B0) * TILE;
-            // (chain(p + 1) runs beside T(p-1): its leaves may count on the reserved CUs only when the blockers were placed before that launch)
-            const bool reserved_before = reserved;
-            // ---- chain stream: Q(p), then chain(p + 1) -----------------------------------------------------------------------------
-            // Q(p) needs chain(p) (same stream), the rows [B1, B2) of panel p (a square launch solved them itself: same stream; else the
-            // column solves of s_top: event) and square p + 1 as T(p-1) -- or, for p = 0, the caller's Gram launch -- left it
-            const bool self_solved = use_sqk(p) && sqk_below(p) == B2 - B1 && B2 > B1;
-            if (!self_solved) GPX_HIP(hipStreamWaitEvent(s_pan, ev_top[p], 0));
-            if (p > 0 && sq_counted) {
-                const int64_t sr = B2 - B1;
-                GPX_TRY(count_wait(s_pan, sigsq + (p - 1), (int)(sr * (sr + 1) / 2)));
-            } else GPX_HIP(hipStreamWaitEvent(s_pan, ev_sq[p], 0));
-            const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
-            // (lower 32 x 32 tiles only: nothing reads the square above its diagonal -- the bulk launches never updated it there)
-            GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
-                                   -1.0, 1.0, 1, s_pan, prof));
-            // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
-            // so neither stream starves while the other's launches are being queued
-            // (exclusive leaf only where a free CU is certain -- reserved CUs, or no bulk launch left)
-            if (use_sqk(p + 1)) GPX_TRY(sqk_launch(p + 1, B1, B2));     // the whole chain of panel p + 1, now
-            else {
-                GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved_before || B2 >= nblk) ? 1 : 0));
-                if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
-            }
-            // ---- main stream: T(p) --------------------------------------------------------------------------------------------------
-            GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));       // diagonal square of panel p is factored
-            GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));      // ... and all rows below it are solved
             if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
                 // (the column solves keep their small tiles and share the reserved CUs with the chain: measured better than 224-register
                 // tiles that stay off them, fit 28.9 -> 28.1 ms)
                 GPX_TRY(reserve_now());
             }
+            const int64_t K = (B1 - B0) * TILE;
+            // (1) only rows [B1,B2) of panel p and the diagonal square of panel p+1 gate the next chain: update that
+            //     square before anything else so that the side stream starts early
+            // (a square launch that solved the rows [B1, B2) itself: the square update below needs nothing else -- the column solves of
+            // the rows further down are waited for behind it, in front of the updates that read them)
+            const bool top_late = piped(p) && use_sqk(p) && sqk_below(p) == B2 - B1 && B2 > B1;
+            if (piped(p) && !top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
+            else if (!piped(p)) GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
+            const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
+            // (lower 32 x 32 tiles only: nothing reads the square above its diagonal -- the bulk launches never updated it there)
+            GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
+                                   -1.0, 1.0, 1, s, prof));
+            GPX_HIP(hipEventRecord(ev_next[p], s));
             // from the first tail panel that runs as a square launch the chain no longer lives on the reserved CUs (a square launch brings
             // its own: one workgroup per CU): the blockers would only keep 32 CUs from the short bulk launches beside it
             if (sqk_from < 0 && use_sqk(p + 1)) release_blockers(s);
-            sq_counted = false;
+            // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
+            // so neither stream starves while the other's launches are being queued
+            {
+                GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+                // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
+                // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
+                if (use_sqk(p + 1)) GPX_TRY(sqk_launch(p + 1, B1, B2));     // the whole chain of panel p + 1, now
+                else {
+                    GPX_TRY(chol_square_steps(L, ld, B1, B2, B1, B1 + 1, Dinv, diagL, info_dev, s_pan, prof, nullptr, (reserved || B2 >= nblk) ? 1 : 0));
+                    if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_first[p], s_pan));
+                }
+            }
+            if (top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));
             if (B2 < nblk) {
+                // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
                 // One trapezoid launch for the next panel's columns AND the bulk SYRK (gemm.hip, launch_syrk_trap_signal): its narrow
-                // tiles come first and are counted in sig[p] per tile column, the tiles of square p + 2 in sigsq[p]; the next panel's
-                // column solves and Q(p + 1) wait for the counts, not for a launch boundary.  Small trailing matrices keep two launches.
+                // tiles come first and are counted in sig[p]; the next panel's column solves wait for the count, not for a launch
+                // boundary.  Small trailing matrices keep the two launches.
                 int merged = GPX_ERR_STATE;
                 const int64_t nrem = nblk - B2;
-                static const long trap_min = [] { const char *e = getenv("GPX_TRAP_MIN_TILES"); return e ? atol(e) : 1024L; }();
+                constexpr long trap_min = 1024;   // (smaller trailing matrices: 100 tiles measured, no difference)
                 if (trap_on && nrem * (nrem + 1) / 2 >= trap_min && B2 - B1 == CHOL_NBP)
                     merged = launch_syrk_trap_signal(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, nrem * TILE, (B2 - B1) * TILE, K, -1.0, 1.0,
-                                                     sig + p * CHOL_NBP, s, prof, sigsq + p);
+                                                     sig + p * CHOL_NBP, s, prof);
                 if (merged != 0 && merged != GPX_ERR_STATE) return merged;
-                sq_counted = merged == 0;
                 // (beside a square kernel the next panel's column solves wait for this launch and the chip is nearly empty: 64 x 64 tiles
-                // finish in a third of a 128 x 128 tile's time)
+                // finish in a third of a 128 x 128 tile's time -- GPX_SQK_NARROW_SMALL)
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Ptop, ld, L + (B2 * TILE) * ld + B1 * TILE, ld, (nblk - B2) * TILE, (B2 - B1) * TILE,
                                            K, -1.0, 1.0, 0, s, prof, 0, 0, (use_sqk(p + 1) && p + 1 > 0) ? 1 : 0));
                 sqk_open_gate(p + 1, s);   // panel p+1's columns have their update: its square launch may solve the rows below its square
                 if (piped(p + 1)) {   // panel p+1's rows below its square are complete: its column solves may start (first column now)
                     if (merged == 0) {
-                        // every column solve waits for its own column's narrow tiles (top_column)
+                        // every column solve waits for its own column's narrow tiles (top_column).  Handing the count over as an event
+                        // from a stream of its own was measured too: one more cross-stream edge per panel, fit +1.4 ms.
                         tops[p + 1].colsig = sig + p * CHOL_NBP;
                         tops[p + 1].colwant = (int)nrem;
+                        tops[p + 1].stall = stall;
                     } else {
                         GPX_HIP(hipEventRecord(ev_tu[p], s));
                         GPX_HIP(hipStreamWaitEvent(s_top, ev_tu[p], 0));
@@ -805,23 +812,21 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     else GPX_HIP(hipStreamWaitEvent(s_top, ev_first[p], 0));
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
+                // (measured: this short bulk launch on 64 x 64 tiles beside a square launch -- no difference)
                 if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                            (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
                 if (bnd(p + 3) >= nblk) release_blockers(s);   // the last bulk launch is queued
             }
-            if (p + 1 < P) GPX_HIP(hipEventRecord(ev_sq[p + 1], s));   // square p + 2 as T(p) leaves it (what Q(p + 1) waits for when nothing counts its tiles)
-            // work of the caller that rides along on the main stream, behind this panel's trailing update (queued before the chain's
-            // remaining launches: a main-stream launch that the host queues behind them starts only when that chain has finished)
+            // work of the caller that rides along on the main stream, behind this panel's trailing update
             if (panel_final) GPX_TRY((*panel_final)(p, (nblk - std::min(B2, nblk) + CHOL_NBP - 1) / CHOL_NBP, false, nullptr));
-            // ---- the rest of chain(p + 1) and S(p + 1) -----------------------------------------------------------------------------
             if (use_sqk(p + 1)) {
                 // the chain runs already (one launch); the column solves of the rows below follow its step counter
                 if (tops[p + 1].stream && tops[p + 1].r1 > tops[p + 1].r0)
                     for (int64_t j = B1 + 1; j < B2; ++j) GPX_TRY(top_column(L, ld, B1, j, Dinv, &tops[p + 1], prof));
             } else
-                GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved_before || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
+            GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
         }
@@ -829,15 +834,16 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     };
     const int rc = run();
     release_blockers(s);
-    (void)hipStreamSynchronize(s_top);
+    if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
     if (s_blk) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(s_blk); stream_release(s_blk, blk_prio); }
     if (ev_blk) (void)hipEventDestroy(ev_blk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
-    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); (void)hipEventDestroy(ev_sq[p]); }
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
+    if (dfl_state) dfree(dfl_state);
     if (sqk_buf) dfree(sqk_buf);
     return rc;
 }

@@ -169,12 +169,16 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
                    hipStream_t s, Profiler *prof, int ktrim = 0, int tri = 0, int small_tiles = 0);
 // narrow update + bulk SYRK of a panel as ONE trapezoid launch that counts its finished narrow tiles in *sig_dev (gemm.hip)
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
-                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof, int *sigsq_dev = nullptr);
+                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof);
 // batched form: problem z = (p, q), q < nq, has its operand at base + p * sp + q * sq (elements)
 // tri (read from the A descriptor; square problems only): the contraction skips the zero part of one triangular operand
 enum { GEMM_TRI_NONE = 0, GEMM_TRI_A_UPPER = 1, GEMM_TRI_A_LOWER = 2, GEMM_TRI_B_LOWER = 3, GEMM_TRI_B_LOWER_PAIRED = 4 /* internal */,
        GEMM_TRI_B_UPPER = 5, GEMM_TRI_B_UPPER_PAIRED = 6 /* internal */ };
 struct GemmBatch { int nq; long sp, sq; int tri; };
+// row reduction in a product's epilogue (gemm.hip, tile_row_reduce): y at C's first column, partial sums [row][nslots]
+struct GemmReduce { const double *y = nullptr; double *p2 = nullptr, *py = nullptr; long slot0 = 0, nslots = 0; };
+int launch_gemm_nt_tri_reduce(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t N,
+                              double alpha, const GemmReduce &red, hipStream_t s, Profiler *prof);
 int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
                            GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);
 int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s);
@@ -209,8 +213,17 @@ int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t
 // out of place, in steps of whole diagonal squares (1024 columns) against their inverses: Zs[:, p0..p1) <- Z[:, p0..p1) L^-T
 // (Z is consumed; p0, p1 in units of squares).  The solver must be prepared for the same factor.
 struct TriSolver;
+// red (optional; p2 / py zeroed by the caller, y = the vector at column 0, nslots = ldz / 64): every slab's leaf product also leaves the
+// row sums  sum_c Zs_rc^2, sum_c Zs_rc y_c  of its columns in the slots of those columns
 int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, const TriSolver *ts, int64_t p0, int64_t p1,
-                          hipStream_t s, Profiler *prof);
+                          hipStream_t s, Profiler *prof, const GemmReduce *red = nullptr);
+int launch_slab_reduce(const double *Zs, int64_t ldz, int64_t rows, int64_t width, const double *y, double *p2, double *py, int64_t nslots, int64_t slot,
+                       hipStream_t s);
+int launch_predict_finish(const double *p2, const double *py, int64_t nslots, int64_t m, double vplusvt, double *mean, double *var, hipStream_t s,
+                          const double *kdiag = nullptr);
+// squares [p0, p0 + np) of a factor inverted into caller buffers (tsolve.hip): pl / pz [np][1024][1024], scratch tt [np][512][512]
+int invert_squares_into(const double *L, int64_t ld, int64_t nblk, const double *Dinv, int64_t p0, int64_t np, double *pl, double *pz, double *tt,
+                        hipStream_t s);
 int build_kinv_from_factor(const double *L, int64_t ld, int64_t nblk, const double *Dinv, double *Z, double *Kinv,
                            hipStream_t s, Profiler *prof);
 // the same from a prepared few-vector solver: its inverted 1024 x 1024 diagonal squares are the leaves (tsolve.hip); Kinv doubles as scratch

@@ -18,10 +18,44 @@
 
 #include "gemm_tile.h"
 
-template <int WM, int WN, bool LOWER>
-__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
-                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
-                                                            GemmBatch ba, GemmBatch bb, GemmBatch bc)
+// Row reduction fused into a product's epilogue (estimate_many: the last product that touches a slab of Zs = kv L^-T is the one with the
+// slab's inverted square -- GaussianProcess.py:77-78 needs only  sum_c z_mc^2  and  sum_c z_mc y_c  of every row): each wave adds up its
+// 64 columns of a row from the accumulators it is about to store and writes the two partial sums to slot 2 bx + wc of that row; a small
+// kernel adds a row's slots in a fixed order.  Saves the separate pass that re-read all of Zs (2.15 GB at N = M = 16384).
+template <int WM, int WN>
+__device__ __forceinline__ void tile_row_reduce(const v4d (&acc)[WM][WN], double alpha, const GemmReduce &red, int bx, int by)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wr = wave >> 1, wc = wave & 1, fr = lane & 15, fq = lane >> 4;
+    const double *yp = red.y + (long)bx * (32 * WN) + wc * (16 * WN) + fr;
+    double yv[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) yv[j] = yp[16 * j];
+    const long slot = red.slot0 + 2 * bx + wc;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double s2 = 0.0, sy = 0.0;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const double z = alpha * acc[i][j][r];
+                s2 = fma(z, z, s2);
+                sy = fma(z, yv[j], sy);
+            }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); sy += __shfl_xor(sy, o); }   // the 16 lanes that share a row
+            if (fr == 0) {
+                const long row = (long)by * (32 * WM) + wr * (16 * WM) + i * 16 + 4 * r + fq;
+                red.p2[row * red.nslots + slot] = s2;
+                red.py[row * red.nslots + slot] = sy;
+            }
+        }
+}
+
+template <int WM, int WN, bool LOWER, bool RED>
+__device__ __forceinline__ void gemm_nt_f64_body(const double *A, long lda, const double *B, long ldb,
+                                                 double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
+                                                 GemmBatch ba, GemmBatch bb, GemmBatch bc, const GemmReduce &red)
 {
     constexpr int BTM = 32 * WM, BTN = 32 * WN;
     __shared__ __attribute__((aligned(1024))) double smem[2 * (BTM + BTN) * 16];
@@ -87,8 +121,30 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
         else if (ba.tri == GEMM_TRI_A_LOWER) kend = min(K, (by + 1) * BTM);            // A[i][k] = 0 for k > i
         else if (ba.tri == GEMM_TRI_B_LOWER || ba.tri == GEMM_TRI_B_LOWER_PAIRED) kend = min(K, (bx + 1) * BTN);   // B[j][k] = 0 for k > j
         else if (ba.tri == GEMM_TRI_B_UPPER || ba.tri == GEMM_TRI_B_UPPER_PAIRED) kstart = (long)bx * BTN;          // B[j][k] = 0 for k < j
-        gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
+        if (RED) {
+            v4d acc[WM][WN];
+            gemm_tile_x<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem, false, acc, GT_INIT | GT_STORE);
+            tile_row_reduce<WM, WN>(acc, alpha, red, bx, by);
+        } else
+            gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
     }
+}
+
+template <int WM, int WN, bool LOWER>
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, long lda, const double *B, long ldb,
+                                                            double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
+                                                            GemmBatch ba, GemmBatch bb, GemmBatch bc)
+{
+    gemm_nt_f64_body<WM, WN, LOWER, false>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri_off, ktrim, tri_rows, ba, bb, bc, GemmReduce{});
+}
+
+// the 128 x 128-tile plain launch with the row reduction in its epilogue (see tile_row_reduce)
+__global__ __launch_bounds__(256, 2) void gemm_nt_f64_reduce_kernel(const double *A, long lda, const double *B, long ldb,
+                                                                   double *C, long ldc, int K, double alpha, double beta, int tri_off,
+                                                                   GemmBatch ba, GemmReduce red)
+{
+    const GemmBatch nb_ = {0, 0, 0, 0};
+    gemm_nt_f64_body<4, 4, false, true>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri_off, 0, 0, ba, nb_, nb_, red);
 }
 
 // One launch for the whole trailing update of a panel: tile rows r = 0 .. nt-1 of C hold `off` full ("narrow") tile columns -- the next
@@ -101,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
 // XCD x (workgroups with blockIdx & 7 == x) takes the narrow 8 x off groups g = x, x + 8, .. (8 tile rows each: 64 tiles that share
 // 8 A and `off` B row panels through that XCD's L2), then its contiguous chunk of the triangle in the grouped order of lower_tile.
 __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const double *A, long lda, const double *B, long ldb, double *C, long ldc,
-                                                                        int K, double alpha, double beta, int off, int nt, int *sig, int *sigsq)
+                                                                        int K, double alpha, double beta, int off, int nt, int *sig)
 {
     __shared__ __attribute__((aligned(1024))) double smem[2 * 256 * 16];
     // 224 registers like the plain bulk kernel (the compiler gets by with 208 here): a wave of this kernel must NOT fit into the 216
@@ -128,17 +184,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const d
         lower_tile(start + idx - mine, 0, nt, by, bx);
         bx += off;
     }
-    // the triangle's first 8 tile rows are the NEXT diagonal square: counted in *sigsq, so that the square's own update (and the chain
-    // behind it, chol.hip) starts on its stream while this launch is still running
-    const bool square = !narrow && sigsq && by < 8;
-    const bool publish = (narrow && sig) || square;
+    const bool publish = narrow && sig;
     gemm_tile<4, 4>(A, lda, B, ldb, C, ldc, bx, by, 0, K, alpha, beta, smem, publish);
     if (publish) {
-        // The tile went out as write-through (sc1) stores: every storing wave drains them, the workgroup meets, one lane
+        // The narrow tile went out as write-through (sc1) stores: every storing wave drains them, the workgroup meets, one lane
         // counts the tile -- no write-back of the XCD's whole L2 (release fence) underneath the running bulk tiles.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(square ? sigsq : sig + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one counter per tile column
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(sig + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one counter per tile column
     }
 }
 
@@ -164,7 +217,7 @@ int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_
 }
 
 int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols, int64_t K,
-                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof, int *sigsq_dev)
+                            double alpha, double beta, int *sig_dev, hipStream_t s, Profiler *prof)
 {
     if (M % TILE || off_cols % TILE || K % GEMM_BK || K <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0) {
         gpx_set_error("launch_syrk_trap_signal: shape/alignment not supported");
@@ -179,7 +232,7 @@ int launch_syrk_trap_signal(const double *A, int64_t lda, const double *B, int64
     }
     ProfScope ps(prof, s, GPX_K_GEMM, (double)nwg * 2.0 * TILE * TILE * (double)K, 1);
     hipLaunchKernelGGL(gemm_nt_f64_trap_signal_kernel, dim3((unsigned)nwg), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, (long)ldc, (int)K, alpha, beta,
-                       (int)off, (int)nt, sig_dev, sigsq_dev);
+                       (int)off, (int)nt, sig_dev);
     GPX_HIP(hipGetLastError());
     return 0;
 }
@@ -262,6 +315,34 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     return 0;
 }
 
+
+// C [M, N] = alpha A B^T with B = a lower-triangular N x N operand (K == N: the zero triangle is skipped) on 128 x 128 tiles, and per row
+// of C the partial sums  sum_c C_rc^2,  sum_c C_rc y_c  of every 64-column piece into red.p2 / red.py [row][red.nslots], slots
+// red.slot0 + (c / 64).  Needs at least 192 tiles (the launch shape of launch_gemm_nt's dominant path).
+int launch_gemm_nt_tri_reduce(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t N,
+                              double alpha, const GemmReduce &red, hipStream_t s, Profiler *prof)
+{
+    const int64_t K = N;
+    const double tiles = (double)(M / TILE) * (double)(N / TILE);
+    if (M % TILE || N % TILE || M <= 0 || N <= 0 || (lda & 1) || (ldb & 1) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || alpha == 0.0 ||
+        tiles < SMALL_GRID_TILES || C == A || C == B || !red.y || !red.p2 || !red.py) {
+        gpx_set_error("launch_gemm_nt_tri_reduce: shape/alignment not supported (M=%ld N=%ld)", (long)M, (long)N);
+        return GPX_ERR_BAD_ARG;
+    }
+    const double kfrac = 0.5 * (1.0 + (double)TILE / (double)K);
+    ProfScope ps(prof, s, GPX_K_GEMM, tiles * 2.0 * TILE * TILE * (double)K * kfrac, 1);
+    if ((N / TILE) % 2 == 0) {
+        const GemmBatch pa_ = {0, 0, 0, GEMM_TRI_B_LOWER_PAIRED};
+        hipLaunchKernelGGL(gemm_nt_f64_reduce_kernel, dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C,
+                           (long)ldc, (int)K, alpha, 0.0, (int)(N / TILE), pa_, red);
+    } else {
+        const GemmBatch na_ = {0, 0, 0, GEMM_TRI_B_LOWER};
+        hipLaunchKernelGGL(gemm_nt_f64_reduce_kernel, dim3((unsigned)(N / TILE), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B, (long)ldb, C,
+                           (long)ldc, (int)K, alpha, 0.0, 0, na_, red);
+    }
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
 
 // batch of independent products C_z = alpha A_z B_z^T + beta C_z, z = (p, q): operand z sits at base + p * sp + q * sq
 // (GemmBatch per operand; nq = number of q per p).  Small problems (the recursive doubling of the diagonal-square
@@ -458,5 +539,5 @@ extern "C" int gpx_dev_gemm_nt(const double *A, int64_t lda, const double *B, in
 extern "C" int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc, int64_t M, int64_t off_cols,
                                  int64_t K, double alpha, double beta, int *count_dev, void *stream)
 {
-    return launch_syrk_trap_signal(A, lda, B, ldb, C, ldc, M, off_cols, K, alpha, beta, count_dev, (hipStream_t)stream, nullptr, nullptr);
+    return launch_syrk_trap_signal(A, lda, B, ldb, C, ldc, M, off_cols, K, alpha, beta, count_dev, (hipStream_t)stream, nullptr);
 }

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__
     // blockIdx.x: [0, 28) sub-diagonal tiles (copy of L), [28, 36) diagonal tiles (copy of Dinv), [36, 68) transposed
     // diagonal tiles, a 32-row strip each
     __shared__ double tr[4][32][33];
-    const int bx = blockIdx.x, p = p_first + blockIdx.y, t = threadIdx.x;
+    const int bx = blockIdx.x, p = p_first + blockIdx.y, ps = blockIdx.y, t = threadIdx.x;   // p: square of the factor, ps: its slot in Pl / Pz
     const int c2 = (t & 63) * 2, r4 = t >> 6;                 // 4 rows x 64 column pairs per pass
     if (bx < 28) {
         int ti = 1;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__
         const long bi = (long)PBT * p + ti, bj = (long)PBT * p + tj;
         const bool valid = bi < nblk;                          // (bj < bi)
         const double *src = L + bi * TILE * ld + bj * TILE;
-        double *dl = Pl + (long)p * PB * PB + (long)ti * TILE * PB + tj * TILE;
+        double *dl = Pl + (long)ps * PB * PB + (long)ti * TILE * PB + tj * TILE;
         for (int r = r4; r < TILE; r += 4) {
             v2d v = (v2d){0.0, 0.0};
             if (valid) v = *reinterpret_cast<const v2d *>(src + (long)r * ld + c2);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__
     const long bi = (long)PBT * p + ti;
     const bool valid = bi < nblk;
     const double *src = Dinv + bi * (long)TILE * TILE;
-    const long doff = (long)p * PB * PB + (long)ti * TILE * PB + ti * TILE;
+    const long doff = (long)ps * PB * PB + (long)ti * TILE * PB + ti * TILE;
     if (bx < 36) {
         double *dl = Pl + doff;
         for (int r = r4; r < TILE; r += 4) {
@@ -239,6 +239,9 @@ __global__ __launch_bounds__(256) void ts_seed_kernel(const double *__restrict__
         for (int r = ty; r < 32; r += 8) dz[(long)(32 * q + r) * PB + sr + tx] = tr[q][tx][r];
 }
 
+int invert_squares_into(const double *L, int64_t ld, int64_t nblk, const double *Dinv, int64_t p0, int64_t np, double *pl, double *pz, double *tt,
+                        hipStream_t s);
+
 int TriSolver::attach(const double *L_, int64_t ld_, int64_t nblk_, const double *Dinv_)
 {
     release();
@@ -260,9 +263,17 @@ int TriSolver::invert_squares(int64_t p0, int64_t p1, hipStream_t s, Profiler *p
 {
     if (!Pl || p0 < 0 || p1 > P || p0 >= p1) { gpx_set_error("TriSolver::invert_squares: bad range"); return GPX_ERR_BAD_ARG; }
     ProfScope ps(prof, s, prof_class, 0.0);
-    const int64_t np = p1 - p0, sp = (int64_t)PB * PB;
-    double *pl = Pl + p0 * sp, *pz = Pz + p0 * sp, *tt = T + p0 * (int64_t)(PB / 2) * (PB / 2);
-    hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)np), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, Pl, Pz, (int)p0);
+    const int64_t sp = (int64_t)PB * PB;
+    return invert_squares_into(L, ld, nblk, Dinv, p0, p1 - p0, Pl + p0 * sp, Pz + p0 * sp, T + p0 * (int64_t)(PB / 2) * (PB / 2), s);
+}
+
+// squares [p0, p0 + np) of the factor (L, Dinv) into pl / pz ([np][1024][1024] each: inverse and its transpose) with scratch tt
+// ([np][512][512]): the building block of TriSolver::invert_squares, also used for ONE square by the multi-GPU host's panel step (chol.hip)
+int invert_squares_into(const double *L, int64_t ld, int64_t nblk, const double *Dinv, int64_t p0, int64_t np, double *pl, double *pz, double *tt,
+                        hipStream_t s)
+{
+    const int64_t sp = (int64_t)PB * PB;
+    hipLaunchKernelGGL(ts_seed_kernel, dim3(68, (unsigned)np), dim3(256), 0, s, L, (long)ld, (long)nblk, Dinv, pl, pz, (int)p0);
     GPX_HIP(hipGetLastError());
     for (int64_t h = TILE; h < PB; h *= 2) {
         const int64_t nq = PB / (2 * h);                  // pairs per square
@@ -407,24 +418,82 @@ int TriSolver::mul_lower(const double *B, int64_t ldb, int nrhs, double *OUT, hi
 // (K = 128 .. 512, launch- and fill-bound at 44 TFLOP/s) it replaces.  Out of place -- a row block's column tiles read
 // the whole 1024-column slab -- so solved slabs live in Zs and the updates read them from there.
 // ------------------------------------------------------------------------------------------------------------------
+// the slab's row sums when its leaf product could not take them along (a short or ragged slab): one wave per row over `width` columns
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double *__restrict__ Zs, long ldz, long rows, long width, const double *__restrict__ y,
+                                                         double *__restrict__ p2, double *__restrict__ py, long nslots, long slot)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    double s2 = 0.0, sy = 0.0;
+    for (long c = lane; c < width; c += 64) {
+        const double z = Zs[row * ldz + c];
+        s2 = fma(z, z, s2);
+        sy = fma(z, y[c], sy);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); sy += __shfl_xor(sy, o); }
+    // the slab owns width / 64 slots: the sums go to the first, the others are cleared
+    if (lane < (width + 63) / 64) { p2[row * nslots + slot + lane] = lane ? 0.0 : s2; py[row * nslots + slot + lane] = lane ? 0.0 : sy; }
+}
+
+int launch_slab_reduce(const double *Zs, int64_t ldz, int64_t rows, int64_t width, const double *y, double *p2, double *py, int64_t nslots, int64_t slot,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, Zs, (long)ldz, (long)rows, (long)width, y, p2, py, (long)nslots, (long)slot);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
+// mean_m = sum over the slots of py, var_m = prior - sum over the slots of p2 (fixed order: deterministic); one wave per row
+__global__ __launch_bounds__(256) void predict_finish_kernel(const double *__restrict__ p2, const double *__restrict__ py, long nslots, long m, double vplusvt,
+                                                            double *__restrict__ mean, double *__restrict__ var, const double *__restrict__ kdiag)
+{
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= m) return;
+    const int lane = threadIdx.x & 63;
+    double s2 = 0.0, sy = 0.0;
+    for (long c = lane; c < nslots; c += 64) { s2 += p2[row * nslots + c]; sy += py[row * nslots + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s2 += __shfl_xor(s2, o); sy += __shfl_xor(sy, o); }
+    if (lane == 0) { mean[row] = sy; var[row] = (kdiag ? kdiag[row] : vplusvt) - s2; }
+}
+
+int launch_predict_finish(const double *p2, const double *py, int64_t nslots, int64_t m, double vplusvt, double *mean, double *var, hipStream_t s,
+                          const double *kdiag)
+{
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(predict_finish_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, p2, py, (long)nslots, (long)m, vplusvt, mean, var, kdiag);
+    GPX_HIP(hipGetLastError());
+    return 0;
+}
+
 int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, const TriSolver *ts, int64_t p0, int64_t p1, hipStream_t s,
-                          Profiler *prof)
+                          Profiler *prof, const GemmReduce *red)
 {
     const int64_t np = p1 - p0;
     if (np <= 0 || rows <= 0) return 0;
     if (!ts || !ts->Pl) { gpx_set_error("trsm_right_lt_squares: solver not prepared"); return GPX_ERR_STATE; }
     if (np == 1) {
         const int64_t k0 = p0 * PB, K = std::min<int64_t>(PB, ts->npad - k0);
-        return launch_gemm_nt(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, K, 1.0, 0.0, 0, s, prof, 0, GEMM_TRI_B_LOWER);
+        if (red && (rows / TILE) * (K / TILE) >= 192) {   // the slab's final values leave this product: their row sums ride in its epilogue
+            GemmReduce r = *red;
+            r.y = red->y + k0;
+            r.slot0 = k0 / 64;
+            return launch_gemm_nt_tri_reduce(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, 1.0, r, s, prof);
+        }
+        GPX_TRY(launch_gemm_nt(Z + k0, ldz, ts->Pl + p0 * (int64_t)PB * PB, PB, Zs + k0, ldz, rows, K, K, 1.0, 0.0, 0, s, prof, 0, GEMM_TRI_B_LOWER));
+        if (red) GPX_TRY(launch_slab_reduce(Zs + k0, ldz, rows, K, red->y + k0, red->p2, red->py, red->nslots, k0 / 64, s));
+        return 0;
     }
     int64_t h = 1;
     while (h * 2 < np) h *= 2;
     const int64_t pm = p0 + h;
-    GPX_TRY(trsm_right_lt_squares(Z, Zs, ldz, rows, ts, p0, pm, s, prof));
+    GPX_TRY(trsm_right_lt_squares(Z, Zs, ldz, rows, ts, p0, pm, s, prof, red));
     // Z[:, pm..p1) -= Zs[:, p0..pm) L[pm..p1, p0..pm)^T
     const int64_t c0 = p0 * PB, cm = pm * PB, c1 = std::min<int64_t>(p1 * PB, ts->npad);
     GPX_TRY(launch_gemm_nt(Zs + c0, ldz, ts->L + cm * ts->ld + c0, ts->ld, Z + cm, ldz, rows, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
-    return trsm_right_lt_squares(Z, Zs, ldz, rows, ts, pm, p1, s, prof);
+    return trsm_right_lt_squares(Z, Zs, ldz, rows, ts, pm, p1, s, prof, red);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -87,7 +87,7 @@ print("JITTER %%g" %% gp._dev().jitter())
 """
 
 
-def test_fit_with_dataflow_schedules_is_bit_identical(tmp_path):
+def test_fit_with_dataflow_schedule_is_bit_identical(tmp_path):
     """the fit's Cholesky handed to the dataflow kernel as a whole (GPX_DFLOW_MAX_BLOCKS above the matrix' 71 block rows; by default only
     no fit goes there): the same tile arithmetic in the same order as the multi-stream schedule -> alpha agrees to the
     last bit; and the stall protocol: with a time limit of 2 us every in-kernel wait expires, the launch aborts, the fit repeats on the

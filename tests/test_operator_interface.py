@@ -57,6 +57,11 @@ def test_from_scratch_operator_fit_predict_likelihood(g):
     ocov = make_rational_quadratic(orc.OracleCovariance)()
     np.testing.assert_allclose(cov._negativeloglikelihood(x, gp.t, th2), ocov._negativeloglikelihood(x, gp.t, th2), rtol=1e-9)
     np.testing.assert_allclose(cov._d_nll_d_theta(x, gp.t, th2), ocov._d_nll_d_theta(x, gp.t, th2), rtol=1e-6, atol=1e-7)
+    # Exact propagation RUNS for this operator in the reference (it reads theta[2:4] = log (l, a) as the ARD weights and the operator's
+    # own kernel as C_ux: UncertaintyPropagation.py:269-290, :323-379) -- a drop-in returns the same numbers, nonsense variance included
+    upe = sk.UncertaintyPropagationExact(gp)
+    np.testing.assert_allclose(upe.propagate_GA(g["rq_u"], g["rq_Sigma"]), g["rq_exact"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(upe.propagate_mean(g["rq_u"], g["rq_Sigma"]), g["rq_exact_mean_only"], rtol=0, atol=1e-9)
     # pickling drops the device handle, the round trip predicts the same (reference pickle test, tests.py:626-659)
     gp2 = pickle.loads(pickle.dumps(gp))
     m2, var2 = gp2.estimate_many(xs)
@@ -103,8 +108,17 @@ def test_gaussian_subclass_with_own_cross_covariance(g):
     np.testing.assert_allclose(va, g["wg_approx"][1], rtol=0, atol=1e-8 * v)
     np.testing.assert_allclose([up._get_variance_dv_h(u, h) for h in range(3)], g["wg_dvh"], rtol=0, atol=1e-8 * v)
     np.testing.assert_allclose(up._getFactor(u, S, 0.02), g["wg_factor"], rtol=1e-5)
-    with pytest.raises(NotImplementedError):
-        sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
+    # Exact propagation on the generic route (round 4 refused it): the reference's class reads the GP through _get_beta / _get_W_inv /
+    # _inv_cov_matrix / _covariance only (UncertaintyPropagation.py:269-290, :323-379) and returns these numbers for this operator --
+    # C_ux from the subclass's scalar kernel on the host, the N and N^2 sums on the device (gpx_propagate_exact_matrix)
+    upe = sk.UncertaintyPropagationExact(gp)
+    me, ve = upe.propagate_GA(u, S)
+    np.testing.assert_allclose(me, g["wg_exact"][0], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(ve, g["wg_exact"][1], rtol=0, atol=1e-8 * v)
+    np.testing.assert_allclose(upe.propagate_mean(u, S), g["wg_exact_mean_only"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(upe.propagate_mean(u, S, g["wg_C_half"]), g["wg_exact_mean_C_half"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(upe.propagate_GA(x[7].copy(), S), g["wg_exact_on_row7"], rtol=0, atol=1e-8 * v)   # u on a training row: the +vt quirk of __call__
+    assert upe.LambdaInv.shape == (3, 3) and upe.normalize_C_corr2 > 0          # the attributes the reference's call leaves behind
 
 
 @pytest.mark.parametrize("route", ["generic", "fused"])

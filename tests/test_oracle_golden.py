@@ -179,6 +179,14 @@ def test_spgp_oracle_matches_reference(name):
     mu, var = gp.estimate_many(xs)
     np.testing.assert_allclose(mu, g["pred_mean"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(var, g["pred_var"], rtol=0, atol=2e-7)
+    assert orc.spgp_scalar_cov(x[0], x[1], th, m) == pytest.approx(float(np.ravel(g["scalar_01"])[0]), abs=1e-11)
+    assert orc.spgp_scalar_cov(x[0], x[0], th, m) == pytest.approx(float(np.ravel(g["scalar_00"])[0]), abs=1e-11)
+    if "exact" in g:
+        # UncertaintyPropagationExact on the SPGP model (the class reads the GP through beta / W_inv / Kinv / _covariance only)
+        u, S = g["exact_u"], g["exact_Sigma"]
+        kern = lambda a, b: orc.spgp_scalar_cov(a, b, th, m)
+        np.testing.assert_allclose(orc.exact_propagate_operator(gp, kern, u, S), np.ravel(g["exact"]), rtol=0, atol=1e-8)
+        assert orc.exact_propagate_operator(gp, kern, u, S, mean_only=True) == pytest.approx(float(g["exact_mean_only"]), abs=1e-8)
 
 
 def test_spgp_reference_nll_agreement():
@@ -243,6 +251,10 @@ def test_generic_operator_oracle_against_reference_golden():
     np.testing.assert_allclose(m, g["rq_pred_mean"], rtol=1e-10, atol=1e-11)
     np.testing.assert_allclose(v, g["rq_pred_var"], rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(gp.estimate(xs[0]), g["rq_est0"], rtol=1e-8, atol=1e-11)
+    # Exact propagation runs for this operator in the reference (it reads theta[2:4] = log (l, a) as ARD weights): same numbers
+    kern = lambda a, b: cov(a, b, th)
+    np.testing.assert_allclose(orc.exact_propagate_operator(gp, kern, g["rq_u"], g["rq_Sigma"]), g["rq_exact"], rtol=0, atol=1e-9)
+    assert orc.exact_propagate_operator(gp, kern, g["rq_u"], g["rq_Sigma"], mean_only=True) == pytest.approx(float(g["rq_exact_mean_only"]), abs=1e-10)
     # (B) GaussianCovariance subclass with its own cov_matrix_ij
     cov = make_warped_gaussian(orc.OracleGaussianCovariance)()
     x, t, xs, th = g["wg_x"], g["wg_t"], g["wg_xs"], g["wg_theta"]
@@ -259,3 +271,9 @@ def test_generic_operator_oracle_against_reference_golden():
     np.testing.assert_allclose(orc.approx_propagate(gp, u, S, cache), g["wg_approx"], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose([orc.approx_dvh(gp, u, h, cache) for h in range(3)], g["wg_dvh"], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(orc.approx_factor(gp, u, S, 0.02, cache), g["wg_factor"], rtol=1e-8)
+    # Exact propagation on the subclass: C_ux from its scalar kernel (the parent's), K^-1 from its own matrix
+    kern = lambda a, b: cov(a, b, th)
+    np.testing.assert_allclose(orc.exact_propagate_operator(gp, kern, u, S), g["wg_exact"], rtol=0, atol=1e-9)
+    assert orc.exact_propagate_operator(gp, kern, u, S, mean_only=True) == pytest.approx(float(g["wg_exact_mean_only"]), abs=1e-10)
+    np.testing.assert_allclose(orc.exact_propagate_operator(gp, kern, x[7].copy(), S), g["wg_exact_on_row7"], rtol=0, atol=1e-9)
+    assert orc.exact_propagate_operator(gp, kern, u, S, C=g["wg_C_half"], mean_only=True) == pytest.approx(float(g["wg_exact_mean_C_half"]), abs=1e-10)

@@ -170,7 +170,7 @@ def spgp_cases():
     from skgpuppy.GaussianProcess import GaussianProcess as GP
     out = {}
 
-    def one(name, x, t, theta_gc, xm, xs, keep_dense=True):
+    def one(name, x, t, theta_gc, xm, xs, keep_dense=True, exact_u=None, exact_S=None):
         m, d = xm.shape
         cov = SPGPCovariance(m)
         theta = np.concatenate([theta_gc, xm.ravel()])
@@ -187,6 +187,14 @@ def spgp_cases():
         c["est0"] = np.array(gp.estimate(xs[0]))
         c["scalar_01"] = np.float64(cov(x[0], x[1], theta))
         c["scalar_00"] = np.float64(cov(x[0], x[0], theta))
+        if exact_u is not None:
+            # UncertaintyPropagationExact on an SPGP model: the class reads the GP through _get_beta / _get_W_inv / _inv_cov_matrix /
+            # _covariance only (UncertaintyPropagation.py:269-290, :323-379), so it runs on the dense SPGP inverse
+            import skgpuppy.UncertaintyPropagation as UP
+            upe = UP.UncertaintyPropagationExact(gp)
+            c["exact_u"], c["exact_Sigma"] = exact_u, exact_S
+            c["exact"] = np.array(upe.propagate_GA(exact_u, exact_S))
+            c["exact_mean_only"] = np.float64(upe.propagate_mean(exact_u, exact_S))
         for k, v in c.items():
             out[name + "__" + k] = v
 
@@ -197,7 +205,7 @@ def spgp_cases():
     thg = np.log(np.array([2.0, 0.01, 0.04, 0.04]))
     xm = xg[rng.choice(100, 10, replace=False)] + 0.25 * rng.randn(10, 2)
     xs = rng.uniform(0, 9, (23, 2))
-    one("grid_m10", xg, tg, thg, xm, xs)
+    one("grid_m10", xg, tg, thg, xm, xs, exact_u=np.array([4.4, 5.3]), exact_S=np.diag([0.02, 0.01]))
 
     x, t, xs, th = synth(300, 3, 41, seed_offset=5)
     xm = x[rng.choice(300, 37, replace=False)] + 0.1 * rng.randn(37, 3)
@@ -251,6 +259,13 @@ def generic_operator_cases():
     out["rq_pred_mean"], out["rq_pred_var"] = gp.estimate_many(xs)
     out["rq_est0"] = np.array(gp.estimate(xs[0]))
     out["rq_beta"] = np.array(gp._get_beta())
+    # UncertaintyPropagationExact talks to the GP through _get_beta / _get_W_inv / _inv_cov_matrix / _covariance only
+    # (UncertaintyPropagation.py:269-290, :323-379): it RUNS for this operator -- _get_W_inv reads theta[2:2+d] (here log l, log a) as
+    # the ARD weights, C_ux is the operator's own kernel -- and a drop-in must return the same numbers
+    upe = UP.UncertaintyPropagationExact(gp)
+    out["rq_u"], out["rq_Sigma"] = np.array([3.0, 2.5]), np.array([[0.02, 0.005], [0.005, 0.03]])
+    out["rq_exact"] = np.array(upe.propagate_GA(out["rq_u"], out["rq_Sigma"]))
+    out["rq_exact_mean_only"] = np.float64(upe.propagate_mean(out["rq_u"], out["rq_Sigma"]))
 
     class WarpedGaussian(GaussianCovariance):
         """GaussianCovariance whose cross-covariance is modulated by the (positive definite) factor 1 + 0.1 cos(xi_0 - xj_0)"""
@@ -281,6 +296,15 @@ def generic_operator_cases():
     out["wg_approx"] = np.array(up.propagate_GA(u, S))
     out["wg_dvh"] = np.array([up._get_variance_dv_h(u, h) for h in range(d)])
     out["wg_factor"] = np.float64(up._getFactor(u, S, 0.02))
+    # Exact propagation on the same operator: C_ux comes from the subclass's scalar kernel (the PARENT's __call__: the subclass
+    # overrides cov_matrix_ij only), K^-1 from its own matrix; also with u on a training row (the +vt quirk of __call__) and through
+    # propagate_mean with a caller-supplied C_ux (UncertaintyPropagation.py:269-276)
+    upe = UP.UncertaintyPropagationExact(gp)
+    out["wg_exact"] = np.array(upe.propagate_GA(u, S))
+    out["wg_exact_mean_only"] = np.float64(upe.propagate_mean(u, S))
+    out["wg_exact_on_row7"] = np.array(upe.propagate_GA(x[7].copy(), S))
+    out["wg_C_half"] = 0.5 * np.array([gp._covariance(u, x[i]) for i in range(n)])
+    out["wg_exact_mean_C_half"] = np.float64(upe.propagate_mean(u, S, out["wg_C_half"]))
     # the quadratic-form helpers with an EXPLICIT Kinv that is not the GP's own (UncertaintyPropagation.py:412-481)
     K2inv = np.linalg.inv(out["wg_K"] + 0.05 * np.eye(n))
     out["wg_K2inv"] = K2inv

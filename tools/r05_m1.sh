@@ -5,7 +5,7 @@ OUT=gpurun_out/${1:-r05_m1}; mkdir -p $OUT
 timeout -k 10 900 python -m pytest tests/test_dataflow.py tests/test_gpu_parity.py -m gpu -x -q -k "dataflow or bit_reproducible or fallback or stalled or jitter or reconstructs or c3_fit or potrf or trapezoid or full_size_properties or fit_golden" > $OUT/tests.log 2>&1; echo "tests rc=$?"
 tail -5 $OUT/tests.log
 B="python bench.py --no-cpu --no-python-api --no-propagate --no-extras"
-for v in "X=1" "GPX_TRAP_MIN_TILES=100" "GPX_RESERVE_TILES=3300" "GPX_RESERVE_TILES=4000" "GPX_SQK_TILES=1600" "GPX_RESERVE_CUS=16"; do
+for v in "X=1" "GPX_PANEL_INV=0" "GPX_RESERVE_CUS=0" "GPX_RESERVE_CUS=16" "GPX_RESERVE_CUS=24" "GPX_RESERVE_MIN_TILES=2000" "GPX_RESERVE_MIN_TILES=500" "GPX_SQK_TILES=1600"; do
   env $v timeout -k 10 120 $B --workload c3 --steps 10 --warmup 3 2> $OUT/c3_$v.err | tail -1 > $OUT/c3_$v.json
   python - "$v" $OUT/c3_$v.json <<'PY'
 import json,sys
@@ -14,7 +14,7 @@ try:
 except Exception as e: print(sys.argv[1],"FAILED",e,flush=True)
 PY
 done
-for v in "X=1" "GPX_DFLOW_MAX_BLOCKS=32"; do
+for v in "X=1"; do
   env $v timeout -k 10 120 $B --workload c2 --steps 20 --warmup 5 2> $OUT/c2_$v.err | tail -1 > $OUT/c2_$v.json
   python - "$v" $OUT/c2_$v.json <<'PY'
 import json,sys
