@@ -34,9 +34,22 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *b_s = smem;               // [d][128]  columns of xj (scaled), k-major so a lane reads 2 adjacent columns
 
-    const long row0 = (long)blockIdx.y * GR_ROWS;
-    const long col0 = (long)blockIdx.x * GR_COLS;
-    if (lower_only && col0 > row0 + (GR_ROWS - 1)) return;   // tile entirely above the diagonal
+    long ry = blockIdx.y, cx = blockIdx.x;
+    if (lower_only == 2) {
+        // 1-D grid over the tiles that touch the lower triangle only (a square launch: rounds 1-4 dispatched the full grid and retired
+        // half of it at once).  Row tile ry (64 rows) needs the column tiles cx <= ry / 2 (128 columns): the row pairs (2m, 2m + 1) hold
+        // m + 1 tiles each, m (m + 1) tiles lie before pair m.
+        const long lid = blockIdx.x;
+        long m = (long)((sqrt(4.0 * (double)lid + 1.0) - 1.0) * 0.5);
+        while (m * (m + 1) > lid) --m;
+        while ((m + 1) * (m + 2) <= lid) ++m;
+        const long rem = lid - m * (m + 1);
+        ry = 2 * m + (rem > m ? 1 : 0);
+        cx = rem > m ? rem - (m + 1) : rem;
+    }
+    const long row0 = ry * GR_ROWS;
+    const long col0 = cx * GR_COLS;
+    if (lower_only && col0 > row0 + (GR_ROWS - 1)) return;   // tile entirely above the diagonal (2-D grid of a non-square lower launch)
 
     const int t = threadIdx.x;
     for (int e = t; e < GR_COLS * d; e += 256) {
@@ -137,6 +150,11 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
     size_t lds = (size_t)GR_COLS * d * sizeof(double);
     double stored = lower_only ? 0.5 * (double)rows_pad * (double)cols_pad : (double)rows_pad * (double)cols_pad;
     ProfScope ps(prof, s, GPX_K_GRAM, 8.0 * stored);
+    if (lower_only && rows_pad == cols_pad && rows_pad % (2 * GR_ROWS) == 0) {
+        const int64_t m = rows_pad / (2 * GR_ROWS);           // row pairs: pair m holds 2 (m + 1) tiles
+        grid = dim3((unsigned)(m * (m + 1)), 1);
+        lower_only = 2;
+    }
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, s, xi_w, (long)n1, xj_w, (long)n2, d, v, add_diag,
                        lower_only, pad_mode, out, (long)ld);
     GPX_HIP(hipGetLastError());
