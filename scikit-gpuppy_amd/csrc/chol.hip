@@ -10,6 +10,7 @@
 // block AND inverts its factor in one launch, both on MFMA out of LDS, so that every triangular solve against a
 // diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -637,7 +638,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     auto sqk_open_gate = [&](int64_t pp, hipStream_t on) {
         if (use_sqk(pp) && sqk_below(pp) > 0) hipLaunchKernelGGL(set_flag_kernel, dim3(1), dim3(1), 0, on, sqk_gate(pp), 1);
     };
-    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), top_events;
+    std::vector<hipEvent_t> ev_pf(P), ev_next(P), ev_top(P + 1), ev_tu(P), ev_first(P), ev_sqp(P), top_events;
     hipEvent_t ev0;
     GPX_HIP(hipEventCreateWithFlags(&ev0, hipEventDisableTiming));
     for (int64_t p = 0; p < P; ++p) {
@@ -646,6 +647,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         GPX_HIP(hipEventCreateWithFlags(&ev_top[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_tu[p], hipEventDisableTiming));
         GPX_HIP(hipEventCreateWithFlags(&ev_first[p], hipEventDisableTiming));
+        GPX_HIP(hipEventCreateWithFlags(&ev_sqp[p], hipEventDisableTiming));
     }
     GPX_HIP(hipEventCreateWithFlags(&ev_top[P], hipEventDisableTiming));
     // CU reservation (above) for the tail of the factorisation: flag and placement counter live behind the status word; the
@@ -688,6 +690,12 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         reserved = true;
         return 0;
     };
+    // GPX_DEBUG: host clock (us since the factorisation's first launch) at which each panel's launches had been queued -- in the tail the
+    // kernels are so short that the HOST's enqueue rate (60 launches per panel) can become the critical path
+    static const bool debug_host = getenv("GPX_DEBUG") != nullptr;
+    auto host_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double host_t0 = debug_host ? host_now() : 0.0;
+    std::vector<double> host_marks;
     auto run = [&]() -> int {
         // Per outer panel p the main stream runs, in order:
         //   update of panel p+1's diagonal square (panel p's rows of that square are solved by then) -> event: the side
@@ -733,6 +741,11 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         }
         if (piped(0)) GPX_HIP(hipEventRecord(ev_top[0], s_top));
         GPX_HIP(hipEventRecord(ev_pf[0], s_pan));
+        // Tail of the factorisation (short trailing updates, issued as separate launches): T(p-1) computes the tiles of diagonal square
+        // p + 1 FIRST, as a launch of their own, and marks them (ev_sqp); the update of that square with panel p -- what chain(p + 1)
+        // waits for -- then runs on the CHAIN's stream right behind chain(p) instead of on the main stream behind all of T(p-1), which
+        // runs beside chain(p) at a fraction of the chip (65 CUs belong to the square launch) and used to end 60-240 us after it.
+        bool sq_split_prev = false;
         for (int64_t p = 0; p < P; ++p) {
             const int64_t B0 = bnd(p), B1 = bnd(p + 1), B2 = bnd(p + 2);
             GPX_HIP(hipStreamWaitEvent(s, ev_pf[p], 0));   // diagonal square of panel p is factored
@@ -754,17 +767,23 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             if (piped(p) && !top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));          // solved column by column alongside the chain
             else if (!piped(p)) GPX_TRY(trsm_right_lt(L + (B1 * TILE) * ld, ld, (nblk - B1) * TILE, L, ld, Dinv, B0, B1, s, prof));
             const double *Ptop = L + (B1 * TILE) * ld + B0 * TILE;         // panel p, rows [B1,B2)
+            const bool q_on_chain = sq_split_prev && piped(p);
+            if (q_on_chain) {
+                // (chain(p) precedes on s_pan; the rows [B1, B2) of panel p: a square launch solved them itself, else the column stream)
+                GPX_HIP(hipStreamWaitEvent(s_pan, ev_sqp[p - 1], 0));
+                if (!top_late) GPX_HIP(hipStreamWaitEvent(s_pan, ev_top[p], 0));
+            }
             // (lower 32 x 32 tiles only: nothing reads the square above its diagonal -- the bulk launches never updated it there)
             GPX_TRY(launch_gemm_nt(Ptop, ld, Ptop, ld, L + (B1 * TILE) * ld + B1 * TILE, ld, (B2 - B1) * TILE, (B2 - B1) * TILE, K,
-                                   -1.0, 1.0, 1, s, prof));
-            GPX_HIP(hipEventRecord(ev_next[p], s));
+                                   -1.0, 1.0, 1, q_on_chain ? s_pan : s, prof));
+            if (!q_on_chain) GPX_HIP(hipEventRecord(ev_next[p], s));
             // from the first tail panel that runs as a square launch the chain no longer lives on the reserved CUs (a square launch brings
             // its own: one workgroup per CU): the blockers would only keep 32 CUs from the short bulk launches beside it
             if (sqk_from < 0 && use_sqk(p + 1)) release_blockers(s);
             // host enqueue order: first step of the chain, then the main stream's bulk work, then the rest of the chain,
             // so neither stream starves while the other's launches are being queued
             {
-                GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
+                if (!q_on_chain) GPX_HIP(hipStreamWaitEvent(s_pan, ev_next[p], 0));
                 // (exclusive only where a free CU is certain -- reserved CUs, or no bulk launch left: next to the main stream's launch, which
                 // becomes ready at the same moment, an exclusive leaf that loses the race for a place waits for a whole CU to drain)
                 if (use_sqk(p + 1)) GPX_TRY(sqk_launch(p + 1, B1, B2));     // the whole chain of panel p + 1, now
@@ -774,6 +793,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 }
             }
             if (top_late) GPX_HIP(hipStreamWaitEvent(s, ev_top[p], 0));
+            sq_split_prev = false;
             if (B2 < nblk) {
                 // (2) the rest of panel p+1's columns, then the bulk SYRK
                 const double *Pr = L + (B2 * TILE) * ld + B0 * TILE;       // panel p, rows >= B2
@@ -813,7 +833,17 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                     GPX_TRY(top_column(L, ld, B1, B1, Dinv, &tops[p + 1], prof));
                 }
                 // (measured: this short bulk launch on 64 x 64 tiles beside a square launch -- no difference)
-                if (merged != 0)
+                const int64_t B3 = bnd(p + 3);
+                if (merged != 0 && p + 2 < P && B3 > B2) {
+                    // the tiles of diagonal square p + 2 first and marked, then the rows below them (trapezoid: the square's columns in
+                    // full, then the triangle): the same tiles with the same arithmetic as the one launch below
+                    GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (B3 - B2) * TILE, (B3 - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+                    GPX_HIP(hipEventRecord(ev_sqp[p], s));
+                    sq_split_prev = true;
+                    if (B3 < nblk)
+                        GPX_TRY(launch_gemm_nt(Pr + ((B3 - B2) * TILE) * ld, ld, Pr, ld, L + (B3 * TILE) * ld + B2 * TILE, ld, (nblk - B3) * TILE,
+                                               (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
+                } else if (merged != 0)
                     GPX_TRY(launch_gemm_nt(Pr, ld, Pr, ld, L + (B2 * TILE) * ld + B2 * TILE, ld, (nblk - B2) * TILE,
                                            (nblk - B2) * TILE, K, -1.0, 1.0, 1, s, prof));
                 // once the remaining bulk launches no longer fill the chip the reservation has nothing left to protect
@@ -829,10 +859,16 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
             GPX_TRY(chol_square_steps(L, ld, B1, B2, B1 + 1, B2, Dinv, diagL, info_dev, s_pan, prof, &tops[p + 1], (reserved || bnd(p + 3) >= nblk) ? 2 : 0));   // reserved CUs, or (last panels) a nearly empty chip: every leaf finds an empty CU
             if (piped(p + 1)) GPX_HIP(hipEventRecord(ev_top[p + 1], s_top));
             GPX_HIP(hipEventRecord(ev_pf[p + 1], s_pan));
+            if (debug_host) host_marks.push_back(host_now() - host_t0);
         }
         return 0;
     };
     const int rc = run();
+    if (debug_host) {
+        fprintf(stderr, "[gpx] host enqueue marks, panel by panel (us): ");
+        for (double m : host_marks) fprintf(stderr, "%.0f ", m);
+        fprintf(stderr, "\n");
+    }
     release_blockers(s);
     if (s_top) (void)hipStreamSynchronize(s_top);
     (void)hipStreamSynchronize(s_pan);   // events must not be destroyed while still referenced by queued waits
@@ -840,7 +876,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     if (ev_blk) (void)hipEventDestroy(ev_blk);
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(ev0);
-    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); }
+    for (int64_t p = 0; p < P; ++p) { (void)hipEventDestroy(ev_pf[p]); (void)hipEventDestroy(ev_next[p]); (void)hipEventDestroy(ev_top[p]); (void)hipEventDestroy(ev_tu[p]); (void)hipEventDestroy(ev_first[p]); (void)hipEventDestroy(ev_sqp[p]); }
     (void)hipEventDestroy(ev_top[P]);
     for (hipEvent_t e : top_events) (void)hipEventDestroy(e);
     if (dfl_state) dfree(dfl_state);
