@@ -446,14 +446,15 @@ def run_single(args):
 
     traffic, traffic_src = None, None
     try:   # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (same workload)
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")) as fpm:
+        pmc_name = "r05_pmc_traffic.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")) else "r04_pmc_traffic.json"
+        with open(os.path.join(ROOT, "profiles", pmc_name)) as fpm:
             pm = json.load(fpm)
         if (args.workload or "c3") == "c3" and g_n:
             # the counter passes serialise kernels, so the library runs its two-launch schedule there (55 dominant launches per step
             # instead of 44: the same tiles); the bytes of a whole step (2 steps in the passes) are spread over this run's launches
             per_step = pm["hbm_bytes_per_launch"] * pm["launches"] / 2.0
             traffic = per_step / (g_n / max(1, args.steps))
-            traffic_src = ("profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction): "
+            traffic_src = ("profiles/" + pmc_name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2 gfx950 correction): "
                            "%.1f GB per step over this run's %.0f dominant launches per step" % (per_step / 1e9, g_n / max(1, args.steps)))
     except Exception:
         pass

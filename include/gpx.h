@@ -41,6 +41,9 @@ extern "C" {
 #define GPX_ERR_HIP       (-2)
 #define GPX_ERR_NO_DEVICE (-3)
 #define GPX_ERR_STATE     (-4)
+/* value of the device status word of gpx_dev_chol_panel / gpx_dev_chol_panel_next when an in-kernel hand-off of the panel step timed out
+ * (GPX_WAIT_LIMIT_MS): the factor is invalid; NOT a non-positive pivot -- never to be answered with the +1e-5 I retry */
+#define GPX_INFO_STALLED  0x3fffffff
 
 typedef struct gpx_handle gpx_handle;
 
@@ -254,9 +257,10 @@ int gpx_dev_syrk_trap(const double *A, int64_t lda, const double *B, int64_t ldb
 int gpx_dev_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset, void *stream);
 
 /* factor block columns [B0,B1) (units of GPX_TILE) of the row-major matrix L (ld, nblk block rows), all updates
- * from columns < B0 already applied: the diagonal square 128 columns at a time on `stream`, the rows below it solved
- * column by column on an internal side stream alongside that chain (forked from and joined back into `stream`).  This is
- * the per-panel step the multi-GPU host (skgpuppy_amd/distributed.py) runs on the panel owner. */
+ * from columns < B0 already applied: the diagonal square on `stream` (128 columns at a time, or -- first panel, short trailing
+ * matrix -- as one square launch of the dataflow kernel), the rows below it solved column by column on an internal side stream
+ * alongside that chain (forked from and joined back into `stream`).  This is the per-panel step the multi-GPU host
+ * (skgpuppy_amd/distributed.py) runs on the panel owner.  *info_dev: 0, the 1-based failing column, or GPX_INFO_STALLED. */
 int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *dinv, double *diag,
                        int *info_dev, void *stream);
 /* the same, preceded by the rank-kp update with the PREVIOUS panel that the block columns [B0,B1) still lack:

@@ -10,6 +10,7 @@
 // block AND inverts its factor in one launch, both on MFMA out of LDS, so that every triangular solve against a
 // diagonal block becomes a GEMM with its inverse.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -326,22 +327,111 @@ static void retire_events(const std::vector<hipEvent_t> &fresh)
     pending.insert(pending.end(), fresh.begin(), fresh.end());
 }
 
-// The same with the rows below the square solved column by column on a side stream alongside the chain (TopPipe, as in
-// chol_factor): the multi-GPU host's panel owner runs this.  Fork / join inside: on return everything is ordered behind `s`.
+// device buffers whose last use is queued on a stream but not waited for by the host: freed (returned to the pool) by a later call, once
+// an event recorded behind that use has passed
+static void retire_buffers(const std::vector<void *> &bufs, hipStream_t behind)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<hipEvent_t, std::vector<void *>>> pending;
+    std::lock_guard<std::mutex> lk(mu);
+    size_t keep = 0;
+    for (size_t i = 0; i < pending.size(); ++i) {
+        if (hipEventQuery(pending[i].first) == hipSuccess) {
+            (void)hipEventDestroy(pending[i].first);
+            for (void *q : pending[i].second) dfree(q);
+        } else {
+            if (keep != i) pending[keep] = std::move(pending[i]);
+            ++keep;
+        }
+    }
+    pending.resize(keep);
+    if (bufs.empty()) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, behind) != hipSuccess) {
+        (void)hipStreamSynchronize(behind);          // (cannot track it: wait, then free)
+        if (e) (void)hipEventDestroy(e);
+        for (void *q : bufs) dfree(q);
+        return;
+    }
+    pending.push_back({e, bufs});
+}
+
+// status words of a square launch (dflow.hip: [0] potrf status, [1] stall) folded into the caller's ONE status word: a non-positive
+// pivot as it is, an expired in-kernel wait as GPX_INFO_STALLED (the multi-GPU host raises on it: that factor is invalid, and it is not
+// a property of K -- never answered with jitter)
+__global__ void merge_info_kernel(const int *two, int *one)
+{
+    if (two[1]) *one = GPX_INFO_STALLED;
+    else if (two[0] && *one == 0) *one = two[0];
+}
+
+// The panel step of the multi-GPU host's panel owner (skgpuppy_amd/distributed.py -> gpx_dev_chol_panel / gpx_dev_chol_panel_next): factor
+// block columns [B0, B1) of the rows >= B0 with the rows below the square solved column by column on a side stream alongside the
+// chain (TopPipe, as in chol_factor).  Fork / join inside: on return everything is ordered behind `s`, nothing is waited for.
+//   P (optional): rows >= B0 * 128 of the PREVIOUS panel (kp columns, leading dimension ldp) whose rank-kp update this panel still
+//   lacks.  The diagonal square gets it first, on `s`, so that the chain starts at once; the rows below get it on the side stream, ahead
+//   of the column solves that need them (the single-GPU schedule's order).
+// Round 5: the chain of the FIRST panel and of the panels with a short trailing matrix (fewer than 1000 tiles of trailing update left:
+// chol_factor's rule -- a square launch needs whole CUs, which a long trailing update beside it does not give up) is ONE square launch
+// of the dataflow kernel (dflow.hip; ~56 us per 128-column step instead of ~100-250 us of dependent launches that wait for places),
+// its column solves follow the launch's step counter.  (A panel solve by one product with the square's inverse was measured here too:
+// slower in the one-rank rehearsal, tools/native/rejected/r05_owner_step_square_launch_product_solve.patch.)
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                             int *info_dev, hipStream_t s, Profiler *prof, const double *P, int64_t ldp, int64_t kp)
 {
-    // P (optional): rows >= B0 * 128 of the PREVIOUS panel (kp columns, leading dimension ldp) whose rank-kp update this
-    // panel still lacks.  The diagonal square gets it first, on `s`, so that the chain starts at once; the rows below
-    // get it on the side stream, ahead of the column solves that need them (the single-GPU schedule's order).
     const int64_t c0 = B0 * TILE, w = (B1 - B0) * TILE, below = (nblk_all - B1) * TILE;
     double *Csq = L + c0 * ld + c0;
     if (P) GPX_TRY(launch_gemm_nt(P, ldp, P, ldp, Csq, ld, w, w, kp, -1.0, 1.0, 0, s, prof));
-    if (nblk_all <= B1) return chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof);
+    const int64_t nrem = nblk_all - B1;
+    static const int64_t sqk_from = [] { const char *e = getenv("GPX_SQK_FROM"); return e ? atol(e) : (int64_t)-2; }();
+    const bool sqk = sqk_from != -1 && B1 - B0 == CHOL_NBP && B0 % CHOL_NBP == 0 && chol_dataflow_supported(CHOL_NBP) &&
+                     (sqk_from == 0 || B0 == 0 || nrem * (nrem + 1) / 2 + nrem * CHOL_NBP < 1000);
+    std::vector<void *> scratch;
+    int *two = nullptr, *state = nullptr, *tab_dev = nullptr;
+    if (sqk) {
+        // status pair, state words and task tables of the launch: zeroed / uploaded on `s` BEFORE the fork, so that the column solves on
+        // the side stream never poll a recycled buffer's old counters
+        static thread_local std::vector<int> tab_host;   // (uploaded asynchronously: must outlive this call)
+        const int64_t nstate = chol_dataflow_state_ints(CHOL_NBP), ntab = chol_dataflow_table_ints(CHOL_NBP);
+        tab_host.assign((size_t)ntab, 0);
+        if (chol_dataflow_fill_tables((int)CHOL_NBP, (int)CHOL_NBP, tab_host.data(), (int)ntab) < 0) { gpx_set_error("chol_panel_factor_piped: task tables"); return GPX_ERR_STATE; }
+        double *buf = nullptr;
+        GPX_TRY(dalloc(&buf, (4 + nstate + ntab) / 2 + 2));
+        scratch.push_back(buf);
+        two = reinterpret_cast<int *>(buf); state = two + 4; tab_dev = state + nstate;
+        GPX_HIP(hipMemsetAsync(two, 0, sizeof(int) * (size_t)(4 + nstate), s));
+        GPX_HIP(hipMemcpyAsync(tab_dev, tab_host.data(), sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, s));
+    }
+    auto chain = [&](const TopPipe *top) -> int {
+        if (!sqk) return chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof, top);
+        static thread_local std::vector<int> tab;
+        GPX_TRY(launch_chol_dataflow(L, ld, B1, B0, Dinv, diagL, two, state, tab, wait_limit_ticks(), s, 32, 1, tab_dev));
+        if (top)
+            for (int64_t j = B0; j < B1; ++j) GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof));
+        return 0;
+    };
+    auto finish_sqk = [&]() -> int {   // on s, behind the launch and (through the join) its column solves
+        if (!sqk) return 0;
+        hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, s, (const int *)two, info_dev);
+        GPX_HIP(hipGetLastError());
+        return 0;
+    };
+    if (below <= 0) {
+        int rc = chain(nullptr);
+        if (!rc) rc = finish_sqk();
+        if (rc) (void)hipStreamSynchronize(s);
+        retire_buffers(scratch, s);
+        return rc;
+    }
     hipStream_t st = stream_acquire(1);
     if (!st) {
         if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, s, prof));
-        return chol_panel_factor(L, ld, nblk_all, B0, B1, Dinv, diagL, info_dev, s, prof);
+        int rc = chain(nullptr);
+        if (!rc) rc = finish_sqk();
+        if (!rc) rc = trsm_right_lt(L + (B1 * TILE) * ld, ld, below, L, ld, Dinv, B0, B1, s, prof);
+        if (rc) (void)hipStreamSynchronize(s);
+        retire_buffers(scratch, s);
+        return rc;
     }
     std::vector<hipEvent_t> events;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -353,23 +443,25 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
         if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, st, prof));
         TopPipe top;
         top.stream = st; top.r0 = B1; top.r1 = nblk_all; top.events = &events;
-        GPX_TRY(chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof, &top));
+        if (sqk) { top.sq_state = state; top.sq_rows = B1 - B0; top.sq_nbr = B1 - B0; top.stall = two + 1; }
+        GPX_TRY(chain(&top));
         GPX_HIP(hipEventRecord(e1, st));
         GPX_HIP(hipStreamWaitEvent(s, e1, 0));
-        return 0;
+        return finish_sqk();
     };
     const int rc = run();
     // No host synchronisation here: the caller goes on queueing its trailing updates while the panel is being factored.
     // The events are still referenced by queued waits, so they retire through a list that later calls sweep once
-    // hipEventQuery says the GPU has passed them; the side stream goes back to the cache (whoever takes it next queues
-    // behind the work it still holds).
+    // hipEventQuery says the GPU has passed them (the launch's state buffer likewise); the side stream goes back to the cache
+    // (whoever takes it next queues behind the work it still holds).
+    if (rc) { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(s); }
+    retire_buffers(scratch, s);
     if (e0) events.push_back(e0);
     if (e1) events.push_back(e1);
     retire_events(events);
     stream_release(st, 1);
     return rc;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // CU reservation for the diagonal chain.  Measured (tools/native/probe_slot.hip, probe_leafk.hip): while a bulk
@@ -572,8 +664,20 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
         if (panel_final) GPX_TRY((*panel_final)(P - 1, 0, true, nullptr));
         return 0;
     };
+    // ONE look-ahead factorisation per device at a time takes the schedule with CU blockers, exclusive square launches and kernels that
+    // wait for counters of other streams: two of them side by side (two host threads, each with a handle of its own) hold 64 CUs with
+    // blockers, compete for whole CUs with their square launches and sit in each other's way for milliseconds (measured: two threads,
+    // four fits each at N = 12288 / 16384, 3.3x the serial sum; no stall, but nothing bounds the wait either).  A fit that finds another
+    // one in flight on its device takes the plain schedule instead (events only, no reservation): the same tile arithmetic, the GPU is
+    // the shared resource either way.
+    struct SoloToken {
+        int dev = 0; bool solo = false;
+        static std::atomic<int> &count(int d) { static std::atomic<int> c[64]; return c[d & 63]; }
+        SoloToken() { (void)hipGetDevice(&dev); solo = count(dev).fetch_add(1) == 0; }
+        ~SoloToken() { count(dev).fetch_sub(1); }
+    } token;
     // (its column solves wait for the kernel's counters from another stream: needs streams that run side by side, like the trapezoid hand-off)
-    const bool concurrent_ok = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    const bool concurrent_ok = token.solo && streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
     // Square-kernel mode: the diagonal chain of a panel -- 8 x (leaf, in-square solve,
     // rank-128 update) = 24 dependent launches -- is ONE small launch of the dataflow kernel on the panel's square (leaf + side workers,
     // dflow.hip), and the column solves of the rows below wait for its step counter instead of for events.
@@ -654,7 +758,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // blockers run on a stream of their own
     // (the waiting kernel on the chain's stream, its release on the main stream: the order in which the fit first uses its streams --
     // the runtime binds a stream to a hardware queue at its first launch, and another order was measured to cost 5 ms per fit)
-    const bool concurrent = streams_run_concurrently(s_pan, s) && (!s_top || streams_run_concurrently(s_top, s));
+    const bool concurrent = concurrent_ok;
     int nres = concurrent ? reserve_cus() : 0;
     // (high priority: that class has its own hardware queues, which an application's ordinary streams do not crowd)
     const int blk_prio = blocker_stream_prio();

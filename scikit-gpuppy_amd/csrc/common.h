@@ -162,7 +162,7 @@ struct gpx_handle {
 // ---- kernels / host launchers implemented across the .hip files -------------------------------
 int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, int d, double v, double add_diag,
                 int lower_only, int pad_mode, double *out, int64_t ld, int64_t rows_pad, int64_t cols_pad,
-                hipStream_t s, Profiler *prof);
+                hipStream_t s, Profiler *prof, const double *colscale = nullptr);   // colscale [n2] (optional): out[i][j] *= colscale[j]
 int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const double *sw_dev, double *out, hipStream_t s);
 int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, double *C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, double alpha, double beta, int lower_only,

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const double *__restric
 __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi, long n1,
                                                   const double *__restrict__ xj, long n2, int d, double v,
                                                   double add_diag, int lower_only, int pad_mode,
-                                                  double *__restrict__ out, long ld)
+                                                  double *__restrict__ out, long ld, const double *__restrict__ colscale)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *b_s = smem;               // [d][128]  columns of xj (scaled), k-major so a lane reads 2 adjacent columns
@@ -96,13 +96,17 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
     }
 
     const long gc = col0 + 2 * lane;
+    // optional factor per COLUMN (SPGP: W^T = (Lambda^-1/2 K_NM)^T is generated as the Gram matrix K_MN with its columns scaled, instead
+    // of transposing a stored K_NM: spgp.hip); columns past n2 are padding and written as such below
+    v2d cs = (v2d){1.0, 1.0};
+    if (colscale) { cs.x = gc < n2 ? colscale[gc] : 0.0; cs.y = gc + 1 < n2 ? colscale[gc + 1] : 0.0; }
     // a tile that touches neither the diagonal nor the padding (all but a few per mille of them) skips the per-entry tests
     if (row0 + GR_ROWS <= n1 && col0 + GR_COLS <= n2 && (col0 >= row0 + GR_ROWS || col0 + GR_COLS <= row0)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             v2d o;
-            o.x = v * exp_nonpos(-0.5 * acc0[r]);
-            o.y = v * exp_nonpos(-0.5 * acc1[r]);
+            o.x = v * exp_nonpos(-0.5 * acc0[r]) * cs.x;
+            o.y = v * exp_nonpos(-0.5 * acc1[r]) * cs.y;
             *reinterpret_cast<v2d *>(&out[(rbase + r) * ld + gc]) = o;
         }
         return;
@@ -110,8 +114,8 @@ __global__ __launch_bounds__(256) void gram_kernel(const double *__restrict__ xi
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const long gr = row0 + wave * 16 + r;
-        double k0 = v * exp_nonpos(-0.5 * acc0[r]);
-        double k1 = v * exp_nonpos(-0.5 * acc1[r]);
+        double k0 = v * exp_nonpos(-0.5 * acc0[r]) * cs.x;
+        double k1 = v * exp_nonpos(-0.5 * acc1[r]) * cs.y;
         if (gr == gc) k0 += add_diag;
         if (gr == gc + 1) k1 += add_diag;
         if (pad_mode != PAD_NONE) {
@@ -139,7 +143,7 @@ int launch_scale_rows(const double *x, int64_t n, int64_t npad, int d, const dou
 // rows_pad % 64 == 0, cols_pad % 128 == 0, ld >= cols_pad, ld even and out 16-byte aligned.
 int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, int d, double v, double add_diag,
                 int lower_only, int pad_mode, double *out, int64_t ld, int64_t rows_pad, int64_t cols_pad,
-                hipStream_t s, Profiler *prof)
+                hipStream_t s, Profiler *prof, const double *colscale)
 {
     if (rows_pad % GR_ROWS || cols_pad % GR_COLS || ld < cols_pad || (ld & 1) || d < 1 || d > GPX_MAX_D) {
         gpx_set_error("launch_gram: bad padding (rows_pad=%ld cols_pad=%ld ld=%ld d=%d)", (long)rows_pad, (long)cols_pad, (long)ld, d);
@@ -156,7 +160,7 @@ int launch_gram(const double *xi_w, int64_t n1, const double *xj_w, int64_t n2, 
         lower_only = 2;
     }
     hipLaunchKernelGGL(gram_kernel, grid, dim3(256), lds, s, xi_w, (long)n1, xj_w, (long)n2, d, v, add_diag,
-                       lower_only, pad_mode, out, (long)ld);
+                       lower_only, pad_mode, out, (long)ld, colscale);
     GPX_HIP(hipGetLastError());
     return 0;
 }

@@ -299,7 +299,9 @@ static int spgp_fit_body(gpx_spgp *h, const double *x, const double *t_centered,
     GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->lam, s, nullptr));
     GPX_TRY(vec_op(VEC_INV_SQRT, n, np, 0.0, h->lam, nullptr, h->ilam, nullptr, s));
     // W^T = (Lambda^-1/2 K_NM)^T ;  B~ = K_M + 1e-5 I + W^T W                   (:856-858)
-    GPX_TRY(spgp_transpose(h, h->Knm, h->ilam, h->Wt));
+    // (generated, not transposed: the Gram matrix of (pseudo-inputs, inputs) with its columns scaled by Lambda^-1/2 is W^T entry for
+    // entry -- the direct differences are symmetric -- and costs one 4.3 GB store at config 5 where the transposing pass read 4.3 GB more)
+    GPX_TRY(launch_gram(h->xbw, m, h->xw, n, d, h->v, 0.0, 0, 1, h->Wt, np, mp, np, s, nullptr, h->ilam));
     GPX_TRY(launch_gram(h->xbw, m, h->xbw, m, d, h->v, 1e-5, 1, 2, h->LB, mp, mp, mp, s, nullptr));
     GPX_TRY(spgp_wtw(h, h->Wt, h->LB, 1.0));
     GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));

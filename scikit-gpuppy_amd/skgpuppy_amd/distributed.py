@@ -442,7 +442,11 @@ class GpxOps(object):
         if self._timed:
             self.timing = {k: float(sum(a.elapsed_time(b) for a, b in v)) for k, v in self._pairs.items()}
             self.timing["panels_owned"] = len(self._pairs["chol_panel_ms"])
-        return int(self.info.item())
+        info = int(self.info.item())
+        if info == 0x3fffffff:       # GPX_INFO_STALLED (include/gpx.h): an in-kernel hand-off of a panel step timed out -- not a property of K
+            raise RuntimeError("rank %d: a hand-off inside a panel step of the sharded factorisation timed out (GPX_WAIT_LIMIT_MS); "
+                               "the factor is invalid" % self.rank)
+        return info
 
 
 def combine_approx_partials(o, Sigma, v, vt):

@@ -33,7 +33,7 @@ def main():
         allk[k] = {"launches": fetch.get(k, write.get(k))[0], "FETCH_SIZE_KB": fetch.get(k, (0, 0.0))[1],
                    "WRITE_SIZE_KB": write.get(k, (0, 0.0))[1]}
     # the dominant kernel: the 128 x 128-tile launches of the MFMA GEMM, incl. the trapezoid launch of the factorisation (same tile body)
-    dom = [k for k in allk if "gemm_nt_f64_kernel<4, 4" in k or "gemm_nt_f64_trap_signal_kernel" in k]
+    dom = [k for k in allk if "gemm_nt_f64_kernel<4, 4" in k or "gemm_nt_f64_trap_signal_kernel" in k or "gemm_nt_f64_reduce_kernel" in k]
     launches = sum(allk[k]["launches"] for k in dom)
     f_raw = sum(allk[k]["FETCH_SIZE_KB"] for k in dom) * 1024.0
     w = sum(allk[k]["WRITE_SIZE_KB"] for k in dom) * 1024.0
@@ -46,8 +46,8 @@ def main():
         "FETCH_SIZE_bytes_corrected": 2.0 * f_raw,
         "WRITE_SIZE_bytes": w,
         "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-B/lane streaming reads (MI355X_MICROARCH.md, HBM); the kernel stages "
-                      "with global_load_lds_dwordx4.  Calibration inside the same run: predict_reduce_kernel (16-B loads) and gram_kernel "
-                      "(16-B stores) have known algorithmic byte counts (2.15 GB read / 2 x 2.15 GB + 1.07 GB written per step), see all_kernels_raw.",
+                      "with global_load_lds_dwordx4.  Calibration inside the same run: gram_kernel "
+                      "(16-B stores) has a known algorithmic byte count (2 x 2.15 GB + 1.07 GB written per step), see all_kernels_raw.",
         "hbm_bytes_per_launch": (2.0 * f_raw + w) / max(launches, 1),
         "all_kernels_raw": allk,
     }
