@@ -40,7 +40,7 @@ def main():
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu --no-propagate --no-extras --no-python-api",
         "workload": "C3: N=16384 d=8 M=16384; every fit+estimate_many step the command runs (timed + untimed profiling step)",
-        "kernel": "gemm_nt_f64_kernel<4,4,*> + gemm_nt_f64_trap_signal_kernel (128x128 tile launches: the bulk of the flops)",
+        "kernel": "gemm_nt_f64_kernel<4,4,*> + gemm_nt_f64_trap_signal_kernel + gemm_nt_f64_reduce_kernel (128x128 tile launches: the bulk of the flops)",
         "launches": launches,
         "FETCH_SIZE_bytes_raw": f_raw,
         "FETCH_SIZE_bytes_corrected": 2.0 * f_raw,
