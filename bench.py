@@ -423,6 +423,9 @@ def run_single(args):
         table_prof, table_steps = prof, 1
     else:
         table_steps = args.steps
+    # the sections below (propagation, Python classes, likelihood, SPGP, C2 / C4) are timed WITHOUT event bracketing: left at level 2
+    # (all ~600 launches of a fit bracketed) the Python-API fit read 28.9 ms where it takes 27.1 (tools/probe_python_overhead.py)
+    os.environ["GPX_PROFILE"] = "0"
     achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
     # known-good references on the same box: (i) the issue rate of v_mfma_f64_16x16x4_f64 itself (gpx_bench_mfma_f64: what `peak`
     # stands for, re-measured here), (ii) the vendor DGEMM (rocBLAS through torch) on an 8192^3 NT product -- best of 5 after 3

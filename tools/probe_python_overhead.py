@@ -1,5 +1,5 @@
-"""Where the Python-class figure of bench.py loses time against the C-ABI figure: gpx_fit on device pointers, on host
-pointers, and through GaussianProcess(...)."""
+"""Where the Python-API fit's extra time over the device-resident C-ABI call goes: gpx_fit with device pointers, with pageable host
+pointers, with pinned host pointers, and GaussianProcess(...) itself (C3 size)."""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scikit-gpuppy_amd"))
@@ -12,24 +12,36 @@ lib = _gpx.lib
 N, d = 16384, 8
 x, t, xs, th = bench.recipe(N, d, N)
 tc = t - t.mean()
-xd = torch.as_tensor(x).cuda(); td = torch.as_tensor(tc).cuda()
+xd, td, xsd = torch.as_tensor(x).cuda(), torch.as_tensor(tc).cuda(), torch.as_tensor(xs).cuda()
+xp, tp, xsp = torch.as_tensor(x).pin_memory(), torch.as_tensor(tc).pin_memory(), torch.as_tensor(xs).pin_memory()
+mean_d = torch.empty(N, dtype=torch.float64, device="cuda"); var_d = torch.empty_like(mean_d)
+mean_h = np.empty(N); var_h = np.empty(N)
+mean_p = torch.empty(N, dtype=torch.float64).pin_memory(); var_p = torch.empty(N, dtype=torch.float64).pin_memory()
 vp = lambda a: ctypes.c_void_p(a.data_ptr())
-def timeit(f, reps=6):
-    best = 1e9
-    for r in range(reps):
-        torch.cuda.synchronize(); a = time.perf_counter(); f(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - a)
-    return best * 1e3
-def fit_dev():
-    h = ctypes.c_void_p(); _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "fit"); lib.gpx_free(h)
-def fit_host():
-    h = ctypes.c_void_p(); _gpx.check(lib.gpx_fit(_gpx.ptr(x), _gpx.ptr(tc), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "fit"); lib.gpx_free(h)
-def fit_py():
-    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), th.copy()); gp._dev().close()
-def fit_only_dev():
-    h = ctypes.c_void_p(); _gpx.check(lib.gpx_fit(vp(xd), vp(td), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "fit"); return h
-print("fit+free, device pointers: %.2f ms" % timeit(fit_dev))
-print("fit+free, host pointers  : %.2f ms" % timeit(fit_host))
-print("GaussianProcess(...)+close: %.2f ms" % timeit(fit_py))
-hs = []
-a = time.perf_counter(); h = fit_only_dev(); b = time.perf_counter(); lib.gpx_free(h); c = time.perf_counter()
-print("fit %.2f ms, free %.3f ms" % ((b - a) * 1e3, (c - b) * 1e3))
+def cyc(xa, ta, xsa, ma, va):
+    best = (1e9, 0, 0)
+    for r in range(8):
+        h = ctypes.c_void_p()
+        torch.cuda.synchronize(); a = time.perf_counter()
+        _gpx.check(lib.gpx_fit(xa, ta, N, d, _gpx.ptr(th), None, ctypes.byref(h)), "fit")
+        b = time.perf_counter()
+        _gpx.check(lib.gpx_predict(h, xsa, N, ma, va), "predict")
+        torch.cuda.synchronize(); c = time.perf_counter()
+        lib.gpx_free(h)
+        if r >= 2 and c - a < best[0]: best = (c - a, b - a, c - b)
+    return best
+for name, args in (("device pointers", (vp(xd), vp(td), vp(xsd), vp(mean_d), vp(var_d))),
+                   ("pageable host pointers", (_gpx.ptr(x), _gpx.ptr(tc), _gpx.ptr(xs), _gpx.ptr(mean_h), _gpx.ptr(var_h))),
+                   ("pinned host pointers", (vp(xp), vp(tp), vp(xsp), vp(mean_p), vp(var_p)))):
+    tot, f, p = cyc(*args)
+    print("%-26s fit %.3f ms  predict %.3f ms" % (name, f * 1e3, p * 1e3), flush=True)
+best = (1e9, 0, 0)
+for r in range(6):
+    a = time.perf_counter()
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), th.copy())
+    b = time.perf_counter()
+    m, v = gp.estimate_many(xs)
+    c = time.perf_counter()
+    gp._dev().close()
+    if r >= 2 and c - a < best[0]: best = (c - a, b - a, c - b)
+print("%-26s fit %.3f ms  predict %.3f ms" % ("GaussianProcess classes", best[1] * 1e3, best[2] * 1e3))
