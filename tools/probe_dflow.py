@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Dataflow factorisation kernel (gpx_dev_chol_dataflow, csrc/dflow.hip): correctness against numpy on small shapes, then the fit's
-time at C3 size by hand-over panel (GPX_DFLOW_FROM is read once per process: one subprocess per setting).
-usage: probe_dflow.py [check|time|fit FROM]"""
+time at C3 size for the multi-stream schedule ("off"), the whole-matrix dataflow launch ("whole": GPX_DFLOW_MAX_BLOCKS above the matrix)
+or any variant given as environment assignments A=1,B=2 (switches are read once per process: one subprocess per setting).  Round 4's
+hand-over panels (GPX_DFLOW_FROM) and the bulk-only diagnostic went with round 5's pruning; `bulk` below needs a round-4 library.
+usage: probe_dflow.py [check|time [off|whole|A=1,B=2 ...]|fit LABEL]"""
 import ctypes
 import os
 import subprocess
@@ -119,15 +121,15 @@ def main():
     elif mode == "fit":
         fit_once(sys.argv[2])
     else:
-        for frm in sys.argv[2:] or ["off", "-6", "-8", "-10", "0"]:
-            if "=" in frm:      # a variant given as environment assignments: A=1,B=2 (the dataflow hand-over stays off)
-                env = dict(os.environ, GPX_DFLOW_FROM="off")
+        for frm in sys.argv[2:] or ["off", "whole"]:
+            if "=" in frm:      # a variant given as environment assignments: A=1,B=2
+                env = dict(os.environ, GPX_DFLOW_MAX_BLOCKS="0")
                 env.update(dict(kv.split("=", 1) for kv in frm.split(",")))
             else:
-                env = dict(os.environ, GPX_DFLOW_FROM=frm)
+                env = dict(os.environ, GPX_DFLOW_MAX_BLOCKS="100000" if frm == "whole" else "0")
             subprocess.run([sys.executable, os.path.abspath(__file__), "fit", frm], env=env, timeout=300)
         base = np.load(os.path.join(ROOT, "gpurun_out", "probe_dflow_beta_off.npy"))
-        for frm in sys.argv[2:] or ["-6", "-8", "-10", "0"]:
+        for frm in sys.argv[2:] or ["whole"]:
             f = os.path.join(ROOT, "gpurun_out", "probe_dflow_beta_%s.npy" % frm)
             if os.path.exists(f) and frm != "off":
                 print("alpha vs off (%s): max abs diff %.3e (scale %.3e)" % (frm, np.abs(np.load(f) - base).max(), np.abs(base).max()))
