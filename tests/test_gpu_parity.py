@@ -141,6 +141,32 @@ def test_gram_empty_and_single():
     assert K.shape == (1, 1) and K[0, 0] == pytest.approx(2.0)
 
 
+@pytest.mark.parametrize("n,d", [(128, 3), (384, 2), (1000, 5), (2176, 8)])
+def test_gram_lower_only_triangular_grid(n, d):
+    """the fit's lower-only Gram launch on its 1-D grid over the tiles that touch the lower triangle (64 x 128 tiles: row pairs (2m, 2m+1)
+    hold m + 1 column tiles each): every entry on or below the diagonal equals the full launch's (incl. +vt on the diagonal and the
+    identity padding), entries in tiles above the staircase are never written.  cov_matrix (Covariance.py:461-464) is the reference."""
+    rng = np.random.RandomState(n + d)
+    x = rng.uniform(0, 10, (n, d))
+    theta = np.log(np.array([1.7, 0.03] + list(rng.uniform(0.02, 0.2, d))))
+    npad = (n + 127) // 128 * 128
+    xd = _dev(x)
+    full = torch.full((npad, npad), -7.0, dtype=torch.float64, device=xd.device)
+    low = torch.full((npad, npad), -7.0, dtype=torch.float64, device=xd.device)
+    vt = float(np.exp(theta[1]))
+    for out, lower in ((full, 0), (low, 1)):
+        _gpx.check(_gpx.lib.gpx_dev_gram(_p(xd), n, _p(xd), n, d, _gpx.ptr(theta), vt, lower, 1, _p(out), npad, npad, npad, None), "gram")
+    torch.cuda.synchronize()
+    F, Lw = full.cpu().numpy(), low.cpu().numpy()
+    il = np.tril_indices(npad)
+    np.testing.assert_array_equal(Lw[il], F[il])
+    np.testing.assert_allclose(F[:n, :n], orc.gram(x, theta), rtol=1e-9, atol=1e-12)   # (oracle: noise already on the diagonal; |a-b|^2 through a GEMM -> absolute accuracy for far pairs)
+    np.testing.assert_array_equal(F[n:, n:], np.eye(npad - n))
+    # a 64 x 128 tile strictly above the diagonal staircase stays untouched
+    if npad >= 256:
+        assert (Lw[0:64, 128:256] == -7.0).all()
+
+
 # ------------------------------------------------------------------------------------------------
 # GP cases against golden vectors of the reference
 # ------------------------------------------------------------------------------------------------

@@ -224,3 +224,27 @@ def test_predict_kv_on_a_fused_handle_equals_predict():
     _gpx.check(_gpx.lib.gpx_predict_kv(gp._dev().handle, _gpx.ptr(kv), M, _gpx.ptr(kd), _gpx.ptr(mean), _gpx.ptr(var)), "gpx_predict_kv")
     np.testing.assert_allclose(mean + gp.meant, m1, rtol=0, atol=1e-12)
     np.testing.assert_allclose(var, v1, rtol=0, atol=1e-12)
+
+
+def test_exact_matrix_entry_rejects_bad_arguments(g):
+    """gpx_propagate_exact_matrix: a handle of another size, missing arrays, a non-positive weight -> GPX_ERR_BAD_ARG (ValueError)"""
+    import ctypes
+    x, t, th = g["wg_x"], g["wg_t"], g["wg_theta"]
+    gp = sk.GaussianProcess(x, t, make_warped_gaussian(sk.GaussianCovariance)(), th.copy())
+    n, d = x.shape
+    xx, w, C = _gpx.f64(x), np.exp(th[2:2 + d]), np.ones(n)
+    u, S = _gpx.f64(g["wg_u"]), _gpx.f64(g["wg_Sigma"])
+    m, v = ctypes.c_double(), ctypes.c_double()
+    call = lambda h, nn, ww, KK=None, bb=None: _gpx.lib.gpx_propagate_exact_matrix(h, KK, bb, _gpx.ptr(xx), nn, d, _gpx.ptr(_gpx.f64(ww)), _gpx.ptr(C),
+                                                                                   _gpx.ptr(u), _gpx.ptr(S), 1.0, ctypes.byref(m), ctypes.byref(v))
+    assert call(gp._dev().handle, n, w) == 0
+    assert call(gp._dev().handle, n - 1, w) == _gpx.GPX_ERR_BAD_ARG          # the handle holds another n
+    assert call(None, n, w) == _gpx.GPX_ERR_BAD_ARG                          # no handle and no explicit Kinv / beta
+    assert call(gp._dev().handle, n, np.concatenate([[0.0], w[1:]])) == _gpx.GPX_ERR_BAD_ARG
+    # explicit K^-1 / beta give the handle's numbers
+    K, b = _gpx.f64(gp.Kinv), _gpx.f64(gp._get_beta())
+    m0, v0 = m.value, v.value
+    assert call(gp._dev().handle, n, w) == 0
+    m0, v0 = m.value, v.value
+    assert call(None, n, w, _gpx.ptr(K), _gpx.ptr(b)) == 0
+    assert m.value == pytest.approx(m0, abs=1e-10) and v.value == pytest.approx(v0, abs=1e-9)
