@@ -41,7 +41,7 @@ extern "C" {
 #define GPX_ERR_HIP       (-2)
 #define GPX_ERR_NO_DEVICE (-3)
 #define GPX_ERR_STATE     (-4)
-/* value of the device status word of gpx_dev_chol_panel / gpx_dev_chol_panel_next when an in-kernel hand-off of the panel step timed out
+/* value of the device status word of gpx_dev_chol_panel / gpx_dev_chol_panel_next / gpx_dev_chol_panel_split when an in-kernel hand-off of the panel step timed out
  * (GPX_WAIT_LIMIT_MS): the factor is invalid; NOT a non-positive pivot -- never to be answered with the +1e-5 I retry */
 #define GPX_INFO_STALLED  0x3fffffff
 
@@ -269,6 +269,18 @@ int gpx_dev_chol_panel(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t 
  * of the column solves (the look-ahead order of the single-GPU factorisation). */
 int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, const double *prev, int64_t ldp,
                             int64_t kp, double *dinv, double *diag, int *info_dev, void *stream);
+/* the same step for a panel whose message travels in TWO parts (skgpuppy_amd/distributed.py, split panel message): the rows below
+ * the square are cut into a HEAD -- the first head_blocks block rows, i.e. the NEXT panel's diagonal square, all its owner needs to start
+ * its own chain -- solved on stream_head, and the rest on stream_far; both trail the chain on `stream` column by column.  prev may be
+ * NULL (first panel: no update).  The two row streams are ordered behind `stream` as it stands at the call and are NOT joined back:
+ * after the call `stream` carries the square, dinv and diag, stream_head the head rows, stream_far the far rows -- each part can be
+ * packed and sent as soon as ITS stream gets there.  Whatever else the row updates need (the arrival of prev's far rows) the caller
+ * orders on stream_head / stream_far before the call.  Three distinct streams; head and far must not be the null stream.
+ * Same arithmetic per tile as gpx_dev_chol_panel_next (the slices only regroup rows): bit-identical factor.
+ * Part of the multi-GPU form of skgpuppy/Covariance.py:179 (the reference factors on one host with scipy/LAPACK). */
+int gpx_dev_chol_panel_split(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, int64_t head_blocks, const double *prev,
+                             int64_t ldp, int64_t kp, double *dinv, double *diag, int *info_dev, void *stream, void *stream_head,
+                             void *stream_far);
 /* the factorisation (first_block = 0) or its trailing part (all updates from the block columns before first_block applied; first_block
  * a multiple of 8) as ONE persistent dataflow launch (csrc/dflow.hip): leaf, column solves, in-panel and trailing updates are tasks that
  * resident workgroups hand to each other through agent-scope counters instead of ~24 dependent launches per 1024-column panel.  This is what

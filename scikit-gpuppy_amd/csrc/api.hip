@@ -421,6 +421,21 @@ extern "C" int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int6
     return chol_panel_factor_piped(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr, prev, ldp, kp);
 }
 
+extern "C" int gpx_dev_chol_panel_split(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, int64_t head_blocks, const double *prev,
+                                        int64_t ldp, int64_t kp, double *dinv, double *diag, int *info_dev, void *stream, void *stream_head,
+                                        void *stream_far)
+{
+    GPX_TRY(gpx_require_device());
+    const bool bad_prev = prev && (ldp < kp || kp <= 0 || kp % 16 || (ldp & 1) || ((uintptr_t)prev & 15));
+    if (!L || !dinv || !diag || !info_dev || B0 < 0 || B1 <= B0 || B1 > nblk || ld < nblk * TILE || head_blocks < 0 || bad_prev ||
+        !stream_head || !stream_far || stream_head == stream_far || stream_head == stream || stream_far == stream) {
+        gpx_set_error("gpx_dev_chol_panel_split: bad arguments (three distinct streams, head and far not the null stream)");
+        return GPX_ERR_BAD_ARG;
+    }
+    return chol_panel_factor_piped(L, ld, nblk, B0, B1, dinv, diag, info_dev, (hipStream_t)stream, nullptr, prev, prev ? ldp : 0, prev ? kp : 0,
+                                   head_blocks, (hipStream_t)stream_head, (hipStream_t)stream_far);
+}
+
 // ---- fit ---------------------------------------------------------------------------------------
 // priority class of the fit's streams: main stream normal, chain and column-solve streams high (GPX_SIDE_PRIO=0: test hook that puts
 // all of them into one class, so that they share hardware queues -- tests/test_gpu_parity.py, fall-back schedules)

@@ -208,6 +208,7 @@ struct TopPipe {
     const int *sq_state = nullptr;
     int64_t sq_rows = 0;                    // block rows of the square
     int64_t sq_nbr = 0;                     // block rows the square launch owns (its state layout: the square's + the rows it solves below)
+    const TopPipe *next = nullptr;          // further slices of the same panel (other rows, other streams) that trail the same chain
 };
 
 // a one-thread kernel that holds the slice's stream until the trapezoid launch has counted column c's narrow tiles (on the device it runs
@@ -271,10 +272,10 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
 {
     // excl: 1 = the step j == B0 runs its leaf exclusively (launch_potrf_leaf), 2 = every step
     for (int64_t j = j0; j < j1; ++j) {
-        const bool piped = top && top->stream && top->r1 > top->r0;
         // row j of the square's factor is final once step j - 1 is through (the stream already waits for it): column j's update now,
         // underneath this step's leaf
-        if (piped) GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof, 1));
+        for (const TopPipe *t = top; t; t = t->next)
+            if (t->stream && t->r1 > t->r0) GPX_TRY(top_column(L, ld, B0, j, Dinv, t, prof, 1));
         GPX_TRY(launch_potrf_leaf(L + (j * TILE) * ld + j * TILE, ld, Dinv + j * (int64_t)TILE * TILE, diagL + j * TILE, info_dev,
                                   (int)(j * TILE), s, prof, excl == 2 || (excl == 1 && j == B0)));
         const int64_t rows_below = B1 - (j + 1);
@@ -290,13 +291,16 @@ static int chol_square_steps(double *L, int64_t ld, int64_t B0, int64_t B1, int6
             GPX_TRY(launch_gemm_nt(Z, ld, Z, ld, L + ((j + 1) * TILE) * ld + (j + 1) * TILE, ld, rows_below * TILE,
                                    rows_below * TILE, TILE, -1.0, 1.0, 0, s, prof));
         }
-        if (top && top->stream && top->r1 > top->r0) {
-            hipEvent_t e;
-            GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            top->events->push_back(e);
-            GPX_HIP(hipEventRecord(e, s));
-            GPX_HIP(hipStreamWaitEvent(top->stream, e, 0));
-            GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof, 2));
+        hipEvent_t e = nullptr;
+        for (const TopPipe *t = top; t; t = t->next) {
+            if (!t->stream || t->r1 <= t->r0) continue;
+            if (!e) {
+                GPX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                t->events->push_back(e);
+                GPX_HIP(hipEventRecord(e, s));
+            }
+            GPX_HIP(hipStreamWaitEvent(t->stream, e, 0));
+            GPX_TRY(top_column(L, ld, B0, j, Dinv, t, prof, 2));
         }
     }
     return 0;
@@ -327,18 +331,21 @@ static void retire_events(const std::vector<hipEvent_t> &fresh)
     pending.insert(pending.end(), fresh.begin(), fresh.end());
 }
 
-// device buffers whose last use is queued on a stream but not waited for by the host: freed (returned to the pool) by a later call, once
-// an event recorded behind that use has passed
-static void retire_buffers(const std::vector<void *> &bufs, hipStream_t behind)
+// device buffers whose last use is queued on one or several streams but not waited for by the host: freed (returned to the pool) by a
+// later call, once events recorded behind those uses have all passed
+static void retire_buffers(const std::vector<void *> &bufs, const std::vector<hipStream_t> &behind)
 {
     static std::mutex mu;
-    static std::vector<std::pair<hipEvent_t, std::vector<void *>>> pending;
+    struct Pending { std::vector<hipEvent_t> events; std::vector<void *> bufs; };
+    static std::vector<Pending> pending;
     std::lock_guard<std::mutex> lk(mu);
     size_t keep = 0;
     for (size_t i = 0; i < pending.size(); ++i) {
-        if (hipEventQuery(pending[i].first) == hipSuccess) {
-            (void)hipEventDestroy(pending[i].first);
-            for (void *q : pending[i].second) dfree(q);
+        bool done = true;
+        for (hipEvent_t e : pending[i].events) done = done && hipEventQuery(e) == hipSuccess;
+        if (done) {
+            for (hipEvent_t e : pending[i].events) (void)hipEventDestroy(e);
+            for (void *q : pending[i].bufs) dfree(q);
         } else {
             if (keep != i) pending[keep] = std::move(pending[i]);
             ++keep;
@@ -346,15 +353,20 @@ static void retire_buffers(const std::vector<void *> &bufs, hipStream_t behind)
     }
     pending.resize(keep);
     if (bufs.empty()) return;
-    hipEvent_t e = nullptr;
-    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, behind) != hipSuccess) {
-        (void)hipStreamSynchronize(behind);          // (cannot track it: wait, then free)
-        if (e) (void)hipEventDestroy(e);
-        for (void *q : bufs) dfree(q);
-        return;
+    Pending fresh;
+    fresh.bufs = bufs;
+    for (hipStream_t st : behind) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+            (void)hipStreamSynchronize(st);          // (cannot track it: wait for this stream instead)
+            if (e) (void)hipEventDestroy(e);
+            continue;
+        }
+        fresh.events.push_back(e);
     }
-    pending.push_back({e, bufs});
+    pending.push_back(std::move(fresh));
 }
+static void retire_buffers(const std::vector<void *> &bufs, hipStream_t behind) { retire_buffers(bufs, std::vector<hipStream_t>{behind}); }
 
 // status words of a square launch (dflow.hip: [0] potrf status, [1] stall) folded into the caller's ONE status word: a non-positive
 // pivot as it is, an expired in-kernel wait as GPX_INFO_STALLED (the multi-GPU host raises on it: that factor is invalid, and it is not
@@ -365,21 +377,28 @@ __global__ void merge_info_kernel(const int *two, int *one)
     else if (two[0] && *one == 0) *one = two[0];
 }
 
-// The panel step of the multi-GPU host's panel owner (skgpuppy_amd/distributed.py -> gpx_dev_chol_panel / gpx_dev_chol_panel_next): factor
-// block columns [B0, B1) of the rows >= B0 with the rows below the square solved column by column on a side stream alongside the
-// chain (TopPipe, as in chol_factor).  Fork / join inside: on return everything is ordered behind `s`, nothing is waited for.
+// The panel step of the multi-GPU host's panel owner (skgpuppy_amd/distributed.py -> gpx_dev_chol_panel / gpx_dev_chol_panel_next /
+// gpx_dev_chol_panel_split): factor block columns [B0, B1) of the rows >= B0 with the rows below the square solved column by column
+// alongside the chain (TopPipe, as in chol_factor).  Nothing is waited for on the host.
 //   P (optional): rows >= B0 * 128 of the PREVIOUS panel (kp columns, leading dimension ldp) whose rank-kp update this panel still
-//   lacks.  The diagonal square gets it first, on `s`, so that the chain starts at once; the rows below get it on the side stream, ahead
-//   of the column solves that need them (the single-GPU schedule's order).
-// Round 5: the chain of the FIRST panel and of the panels with a short trailing matrix (fewer than 1000 tiles of trailing update left:
+//   lacks.  The diagonal square gets it first, on `s`, so that the chain starts at once; the rows below get it on their slice's stream,
+//   ahead of the column solves that need them (the single-GPU schedule's order).
+//   Slices of the rows below: without caller streams ONE slice on an internal stream, forked from and joined back into `s` (on return
+//   everything is ordered behind `s`).  With caller streams (sh, sf; round 5, the split panel message): the first `hb` block rows -- the
+//   NEXT panel's square, what its owner needs to start its chain -- on sh, the rest on sf; both are ordered behind `s` as it stood at
+//   the call (plus the square's update), are NOT joined back, and the caller orders whatever else their updates need (the arrival of
+//   P's far rows) on those streams before the call.  After the call `s` holds the square, Dinv and diag; sh the head rows; sf the rest.
+// The chain of the FIRST panel and of the panels with a short trailing matrix (fewer than 1000 tiles of trailing update left:
 // chol_factor's rule -- a square launch needs whole CUs, which a long trailing update beside it does not give up) is ONE square launch
 // of the dataflow kernel (dflow.hip; ~56 us per 128-column step instead of ~100-250 us of dependent launches that wait for places),
 // its column solves follow the launch's step counter.  (A panel solve by one product with the square's inverse was measured here too:
 // slower in the one-rank rehearsal, tools/native/rejected/r05_owner_step_square_launch_product_solve.patch.)
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
-                            int *info_dev, hipStream_t s, Profiler *prof, const double *P, int64_t ldp, int64_t kp)
+                            int *info_dev, hipStream_t s, Profiler *prof, const double *P, int64_t ldp, int64_t kp,
+                            int64_t hb, hipStream_t sh, hipStream_t sf)
 {
-    const int64_t c0 = B0 * TILE, w = (B1 - B0) * TILE, below = (nblk_all - B1) * TILE;
+    const int64_t c0 = B0 * TILE, w = (B1 - B0) * TILE;
+    const bool own_streams = sh && sf;
     double *Csq = L + c0 * ld + c0;
     if (P) GPX_TRY(launch_gemm_nt(P, ldp, P, ldp, Csq, ld, w, w, kp, -1.0, 1.0, 0, s, prof));
     const int64_t nrem = nblk_all - B1;
@@ -390,7 +409,7 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
     int *two = nullptr, *state = nullptr, *tab_dev = nullptr;
     if (sqk) {
         // status pair, state words and task tables of the launch: zeroed / uploaded on `s` BEFORE the fork, so that the column solves on
-        // the side stream never poll a recycled buffer's old counters
+        // the slices' streams never poll a recycled buffer's old counters
         static thread_local std::vector<int> tab_host;   // (uploaded asynchronously: must outlive this call)
         const int64_t nstate = chol_dataflow_state_ints(CHOL_NBP), ntab = chol_dataflow_table_ints(CHOL_NBP);
         tab_host.assign((size_t)ntab, 0);
@@ -406,60 +425,82 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
         if (!sqk) return chol_square_steps(L, ld, B0, B1, B0, B1, Dinv, diagL, info_dev, s, prof, top);
         static thread_local std::vector<int> tab;
         GPX_TRY(launch_chol_dataflow(L, ld, B1, B0, Dinv, diagL, two, state, tab, wait_limit_ticks(), s, 32, 1, tab_dev));
-        if (top)
-            for (int64_t j = B0; j < B1; ++j) GPX_TRY(top_column(L, ld, B0, j, Dinv, top, prof));
+        for (int64_t j = B0; j < B1; ++j)
+            for (const TopPipe *t = top; t; t = t->next) GPX_TRY(top_column(L, ld, B0, j, Dinv, t, prof));
         return 0;
     };
-    auto finish_sqk = [&]() -> int {   // on s, behind the launch and (through the join) its column solves
+    auto merge_info = [&](hipStream_t on) -> int {   // behind the launch (on s) / behind a slice's waits (its stall word)
         if (!sqk) return 0;
-        hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, s, (const int *)two, info_dev);
+        hipLaunchKernelGGL(merge_info_kernel, dim3(1), dim3(1), 0, on, (const int *)two, info_dev);
         GPX_HIP(hipGetLastError());
         return 0;
     };
-    if (below <= 0) {
-        int rc = chain(nullptr);
-        if (!rc) rc = finish_sqk();
-        if (rc) (void)hipStreamSynchronize(s);
-        retire_buffers(scratch, s);
-        return rc;
+    // the slices of the rows below the square
+    struct Slice { hipStream_t st; int64_t r0, r1; bool joined; };
+    std::vector<Slice> slices;
+    hipStream_t st_int = nullptr;
+    if (nrem > 0) {
+        if (own_streams) {
+            const int64_t h = hb < 0 ? 0 : (hb > nrem ? nrem : hb);
+            if (h > 0) slices.push_back({sh, B1, B1 + h, false});
+            if (h < nrem) slices.push_back({sf, B1 + h, nblk_all, false});
+        } else if ((st_int = stream_acquire(1)) != nullptr) {
+            slices.push_back({st_int, B1, nblk_all, true});
+        }
     }
-    hipStream_t st = stream_acquire(1);
-    if (!st) {
-        if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, s, prof));
-        int rc = chain(nullptr);
-        if (!rc) rc = finish_sqk();
-        if (!rc) rc = trsm_right_lt(L + (B1 * TILE) * ld, ld, below, L, ld, Dinv, B0, B1, s, prof);
+    if (slices.empty()) {   // no rows below -- or no second stream to be had: everything on s
+        int rc = 0;
+        if (nrem > 0 && P) rc = launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, nrem * TILE, w, kp, -1.0, 1.0, 0, s, prof);
+        if (!rc) rc = chain(nullptr);
+        if (!rc) rc = merge_info(s);
+        if (!rc && nrem > 0) rc = trsm_right_lt(L + (B1 * TILE) * ld, ld, nrem * TILE, L, ld, Dinv, B0, B1, s, prof);
         if (rc) (void)hipStreamSynchronize(s);
         retire_buffers(scratch, s);
         return rc;
     }
     std::vector<hipEvent_t> events;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<TopPipe> tops(slices.size());
     auto run = [&]() -> int {
+        hipEvent_t e0 = nullptr;
         GPX_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        GPX_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        events.push_back(e0);
         GPX_HIP(hipEventRecord(e0, s));
-        GPX_HIP(hipStreamWaitEvent(st, e0, 0));
-        if (P) GPX_TRY(launch_gemm_nt(P + w * ldp, ldp, P, ldp, Csq + w * ld, ld, below, w, kp, -1.0, 1.0, 0, st, prof));
-        TopPipe top;
-        top.stream = st; top.r0 = B1; top.r1 = nblk_all; top.events = &events;
-        if (sqk) { top.sq_state = state; top.sq_rows = B1 - B0; top.sq_nbr = B1 - B0; top.stall = two + 1; }
-        GPX_TRY(chain(&top));
-        GPX_HIP(hipEventRecord(e1, st));
-        GPX_HIP(hipStreamWaitEvent(s, e1, 0));
-        return finish_sqk();
+        for (size_t i = 0; i < slices.size(); ++i) {
+            const Slice &sl = slices[i];
+            GPX_HIP(hipStreamWaitEvent(sl.st, e0, 0));
+            if (P) GPX_TRY(launch_gemm_nt(P + (sl.r0 * TILE - c0) * ldp, ldp, P, ldp, L + (sl.r0 * TILE) * ld + c0, ld, (sl.r1 - sl.r0) * TILE, w, kp,
+                                          -1.0, 1.0, 0, sl.st, prof));
+            TopPipe &top = tops[i];
+            top.stream = sl.st; top.r0 = sl.r0; top.r1 = sl.r1; top.events = &events;
+            if (sqk) { top.sq_state = state; top.sq_rows = B1 - B0; top.sq_nbr = B1 - B0; top.stall = two + 1; }
+            top.next = i + 1 < slices.size() ? &tops[i + 1] : nullptr;
+        }
+        GPX_TRY(chain(&tops[0]));
+        for (const Slice &sl : slices) {
+            if (sl.joined) {
+                hipEvent_t e1 = nullptr;
+                GPX_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                events.push_back(e1);
+                GPX_HIP(hipEventRecord(e1, sl.st));
+                GPX_HIP(hipStreamWaitEvent(s, e1, 0));
+            } else {
+                GPX_TRY(merge_info(sl.st));   // (a wait of this slice that expired: its stream is not joined into s)
+            }
+        }
+        return merge_info(s);
     };
     const int rc = run();
     // No host synchronisation here: the caller goes on queueing its trailing updates while the panel is being factored.
     // The events are still referenced by queued waits, so they retire through a list that later calls sweep once
-    // hipEventQuery says the GPU has passed them (the launch's state buffer likewise); the side stream goes back to the cache
-    // (whoever takes it next queues behind the work it still holds).
-    if (rc) { (void)hipStreamSynchronize(st); (void)hipStreamSynchronize(s); }
-    retire_buffers(scratch, s);
-    if (e0) events.push_back(e0);
-    if (e1) events.push_back(e1);
+    // hipEventQuery says the GPU has passed them (the launch's state buffer likewise, behind every stream that polls it); the internal
+    // stream goes back to the cache (whoever takes it next queues behind the work it still holds).
+    std::vector<hipStream_t> behind{s};
+    for (const Slice &sl : slices) if (!sl.joined) behind.push_back(sl.st);
+    if (rc) for (hipStream_t q : behind) (void)hipStreamSynchronize(q);
+    if (rc && st_int) (void)hipStreamSynchronize(st_int);
+    retire_buffers(scratch, behind);
     retire_events(events);
-    stream_release(st, 1);
+    if (st_int) stream_release(st_int, 1);
     return rc;
 }
 

@@ -206,7 +206,8 @@ void chol_force_plain_schedule(bool on);
 int chol_panel_factor(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                       int *info_dev, hipStream_t s, Profiler *prof);
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, double *Dinv, double *diagL,
-                            int *info_dev, hipStream_t s, Profiler *prof, const double *P = nullptr, int64_t ldp = 0, int64_t kp = 0);
+                            int *info_dev, hipStream_t s, Profiler *prof, const double *P = nullptr, int64_t ldp = 0, int64_t kp = 0,
+                            int64_t head_blocks = 0, hipStream_t s_head = nullptr, hipStream_t s_far = nullptr);
 // Z[rows, c0*128 : c1*128) <- Z * L[c0:c1, c0:c1]^-T   (Z row-major, ldz)
 int trsm_right_lt(double *Z, int64_t ldz, int64_t rows, const double *L, int64_t ldl, const double *Dinv,
                   int64_t c0, int64_t c1, hipStream_t s, Profiler *prof);

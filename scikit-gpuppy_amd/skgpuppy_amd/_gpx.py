@@ -88,6 +88,8 @@ SIGNATURES = {
     "gpx_dev_potrf_leaf": (_int, [_dp, _i64, _dp, _dp, ctypes.c_void_p, _int, ctypes.c_void_p]),
     "gpx_dev_chol_panel": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_dev_chol_panel_next": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
+    "gpx_dev_chol_panel_split": (_int, [_dp, _i64, _i64, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_dev_chol_dataflow": (_int, [_dp, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_adopt_factor": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.c_void_p, ctypes.POINTER(_hp)]),
 }

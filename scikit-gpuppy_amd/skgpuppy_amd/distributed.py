@@ -6,14 +6,17 @@ right-looking Cholesky (csrc/chol.hip):
 
   * the N x N matrix is cut into outer panels of PANEL_BLOCKS x 128 columns; rank r owns panels p = r (mod R);
   * K-build: every rank assembles only the Gram columns of its own panels (no communication);
-  * factorisation, per panel p: the owner factors it on a high-priority side stream (gpx_dev_chol_panel: diagonal chain
-    with the rows below solved column by column alongside), the panel (rows from its diagonal down, 1024 wide) with its
-    inverted diagonal blocks and diagonal is BROADCAST as ONE contiguous message (the path's one real exchange step;
+  * factorisation, per panel p: the owner factors it on high-priority streams (gpx_dev_chol_panel_split: diagonal chain
+    with the rows below solved column by column alongside), the panel is BROADCAST (the path's one real exchange step;
     large messages go as scatter + all-gather, which keeps all seven xGMI links of the source busy instead of one
     ring), every rank applies the rank-1024 update to the panels it owns, reading the panel straight from the receive
-    buffer.  Look-ahead: the owner of panel p+1 updates and factors it first, on the side stream, and its broadcast is
-    posted from there, so factorisation and transfer overlap with the remaining updates of step p on the main stream;
-  * two pre-allocated staging buffers per rank (panels p and p+1); received panels are copied into the rank's own L
+    buffer.  The message travels in TWO parts: the HEAD -- the rows of the NEXT panel's diagonal square, all its owner
+    needs to start its own chain -- as soon as the chain and those rows' solves are through, the TAIL (the rows below,
+    the panel's own square, its inverted diagonal blocks and diagonal) when the far rows are solved: the next chain
+    runs underneath the far rows' solves and transfer instead of behind them.  Look-ahead: the owner of panel p+1
+    updates and factors it first, off the main stream, and its broadcasts are posted from there, so factorisation and
+    transfer overlap with the remaining updates of step p on the main stream;
+  * three pre-allocated staging buffers per rank; received panels are copied into the rank's own L
     off the critical path, so after the last step all ranks hold the complete factor (34 GB at N = 65536: fits one
     288 GB MI355X) and `estimate_many` shards the QUERIES with no further communication; alpha is solved
     redundantly per rank (two HBM-bound sweeps, no exchange);
@@ -40,7 +43,12 @@ JITTER = 1e-5        # skgpuppy/Covariance.py:182
 class PanelLayout(object):
     """Block-cyclic ownership of outer column panels."""
 
-    def __init__(self, n, world, panel_blocks=PANEL_BLOCKS):
+    def __init__(self, n, world, panel_blocks=PANEL_BLOCKS, split=None):
+        # split: the panel message travels as head + tail.  Default: whenever there is a message at all (world > 1; a group of one
+        # rank gains nothing from the extra row slice -- 36.6 against 34.8 ms per C3 fit in the one-rank rehearsal);
+        # GPX_PANEL_MESSAGE=split / whole overrides
+        env = os.environ.get("GPX_PANEL_MESSAGE", "")
+        self.split = (env == "split" or (env != "whole" and int(world) > 1)) if split is None else bool(split)
         self.n = int(n)
         self.npad = (self.n + TILE - 1) // TILE * TILE
         self.nblk = self.npad // TILE
@@ -59,10 +67,27 @@ class PanelLayout(object):
         return [p for p in range(self.npanels) if self.owner(p) == rank]
 
     def message_elems(self, p):
-        """doubles in the broadcast message of panel p: rows from the diagonal down x width | inverted diagonal blocks | diagonal"""
+        """doubles in the message of panel p: rows BELOW its square x width | its square | inverted diagonal blocks | diagonal"""
         b0, b1 = self.blocks(p)
         w = (b1 - b0) * TILE
         return (self.npad - b0 * TILE) * w + (b1 - b0) * TILE * TILE + w
+
+    def head_rows(self, p):
+        """rows of panel p's message that travel first: those of the NEXT panel's diagonal square (0: the message is not split)"""
+        if not self.split or p + 1 >= self.npanels:
+            return 0
+        n0, n1 = self.blocks(p + 1)
+        return (n1 - n0) * TILE
+
+    def parts(self, p):
+        """the parts of panel p's message in the order every rank posts them"""
+        return ("head", "tail") if self.head_rows(p) > 0 else ("tail",)
+
+    def part_range(self, p, part):
+        """[lo, hi) of the part in the message (doubles)"""
+        b0, b1 = self.blocks(p)
+        cut = self.head_rows(p) * (b1 - b0) * TILE
+        return (0, cut) if part == "head" else (cut, self.message_elems(p))
 
 
 def panel_cholesky(ops, layout, rank, comm):
@@ -70,12 +95,12 @@ def panel_cholesky(ops, layout, rank, comm):
     when this rank's `ops` holds the complete factor.
 
     ops : build_panel(p)                      assemble an owned panel
-          factor_panel(p, prev)               owner: apply panel `prev` (or None) to panel p, factor it, fill and return its message buffer
-          recv_buffer(p)                      non-owner: the buffer panel p's message is received into
-          adopt_panel(p, buf, work)           everyone, once per panel, in order: `work.wait()` and make the panel the update operand
+          factor_panel(p, prev)               owner: apply panel `prev` (or None) to panel p, factor it, fill its message
+          message(p, part)                    the buffer of that part of panel p's message (owner: filled; others: to receive into)
+          adopt(p, part, buf, work)           everyone, once per part, in order: `work.wait()`; after the tail the panel is the update operand
           update_panels(qs, p)                apply panel p to the owned panels qs (ascending)
           finish()                            -> this rank's info word
-    comm: broadcast(buf, src, ops) -> work with .wait()   (asynchronous; posted by every rank in panel order)
+    comm: broadcast(buf, src, ops, part) -> work with .wait()   (asynchronous; posted by every rank in panel order, head before tail)
           max_int(v) -> the maximum of v over the ranks
     """
     P = layout.npanels
@@ -84,18 +109,24 @@ def panel_cholesky(ops, layout, rank, comm):
         ops.build_panel(p)
 
     def post(p, prev):
-        """owner: (update with `prev`,) factor, pack; everyone: post the asynchronous broadcast of panel p."""
+        """owner: (update with `prev`,) factor, pack; everyone: post the asynchronous broadcasts of panel p's parts."""
         src = layout.owner(p)
-        buf = ops.factor_panel(p, prev) if src == rank else ops.recv_buffer(p)
-        return buf, comm.broadcast(buf, src, ops)
+        if src == rank:
+            ops.factor_panel(p, prev)
+        out = []
+        for part in layout.parts(p):
+            buf = ops.message(p, part)
+            out.append((part, buf, comm.broadcast(buf, src, ops, part)))
+        return out
 
     inflight = post(0, None)
     for p in range(P):
-        buf, work = inflight
-        ops.adopt_panel(p, buf, work)
+        for part, buf, work in inflight:
+            ops.adopt(p, part, buf, work)
         nxt = p + 1
         # host order: the (single, cheap to queue) trailing update first, then the next panel's long chain of small
-        # launches -- on the device they run side by side on their own streams, ordered by events only
+        # launches -- on the device they run side by side on their own streams, ordered by events only: the next owner's chain
+        # is gated on the HEAD's arrival alone, the rows below its square and the main stream's updates on the tail's
         ops.update_panels([q for q in mine if q > nxt], p)
         if nxt < P:
             inflight = post(nxt, p)          # the owner of the next panel updates + factors it off the main stream
@@ -178,9 +209,9 @@ class TorchComm(object):
             sys.stderr.write("[skgpuppy_amd.distributed] panel transport: plain broadcast\n")
         return ok
 
-    def broadcast(self, buf, src, ops=None):
+    def broadcast(self, buf, src, ops=None, part="tail"):
         dist = self.dist
-        ctx = ops.comm_stream_context() if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
+        ctx = ops.comm_stream_context(part) if ops is not None and hasattr(ops, "comm_stream_context") else _NullContext()
         with ctx:
             n = buf.numel()
             if self.world == 1 and not self.exercise_single_rank:
@@ -228,7 +259,7 @@ class HostStagedComm(object):
         self.dist = dist
         self.group = group
 
-    def broadcast(self, buf, src, ops=None):
+    def broadcast(self, buf, src, ops=None, part="tail"):
         comm = self
 
         class _W(object):
@@ -251,11 +282,15 @@ class HostStagedComm(object):
 # ---------------------------------------------------------------------------------------------------
 # product ops: libgpx kernels on this rank's GPU
 # ---------------------------------------------------------------------------------------------------
+NSLOTS = 3           # staging buffers per rank: panel p's message lives in slot p % 3 (its previous tenant, p - 3, was read steps ago)
+
+
 class GpxOps(object):
-    """Two streams per rank: `main` (the caller's current stream) carries the trailing updates, `side` (high priority)
-    the critical path of the NEXT panel -- its update, factorisation, packing and, on its owner, the broadcast post --
-    plus the copies of received panels into L.  Two staging buffers hold the messages of panels p and p+1; events order
-    every reuse of a buffer behind its last readers on both streams."""
+    """Streams per rank: `main` (the caller's current stream) carries the trailing updates; three high-priority streams carry the
+    critical path of the NEXT panel on its owner -- `side` the square's update and the chain, `head` the rows of the panel after it
+    (update, column solves, pack, the head's broadcast), `far` the rows below (update, column solves, pack, the tail's broadcast) --
+    and `copy` the copies of received panels into L.  Three staging buffers hold the messages of panels p-1, p, p+1; events order
+    every reuse of a buffer behind its last readers on every stream."""
 
     def __init__(self, x_dev, theta, layout, device, rank=0, jitter=0.0):
         import torch
@@ -280,18 +315,30 @@ class GpxOps(object):
         self.info = torch.zeros(1, dtype=torch.int32, device=device)
         self.main = torch.cuda.current_stream(device)
         self.side = torch.cuda.Stream(device=device, priority=-1)
-        self.stage = [torch.empty(layout.message_elems(0), dtype=torch.float64, device=device) for _ in range(2)]
+        self.head = torch.cuda.Stream(device=device, priority=-1)
+        self.far = torch.cuda.Stream(device=device, priority=-1)
+        self.copy = torch.cuda.Stream(device=device)
+        self.stage = [torch.empty(layout.message_elems(0), dtype=torch.float64, device=device) for _ in range(NSLOTS)]
         self._operand = {}                              # panel -> (device pointer, leading dimension, first row) of its update operand
-        self._ev_avail = {}                             # panel -> event: message complete (recorded on main)
-        self._ev_main_done = {}                         # panel -> event: main's updates with that panel are queued
-        # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's panel step (side stream) and around the main stream's wait for
-        # each panel's message -- what the first multi-GPU run is judged on (projected timeline)
+        self._ev_head = {}                              # panel -> event: the rows of the next panel's square are there (no head part: = tail)
+        self._ev_tail = {}                              # panel -> event: the whole message is there
+        self._ev_lookahead = {}                         # panel -> event: the main stream has applied every panel but the last one to it
+        self._readers = {}                              # panel -> events behind every read of its message buffer
+        # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's chain (side stream; chol_panel_ms), from the chain's start to the
+        # last row's solve (far stream; chol_panel_rows_ms = the whole panel step), around the side stream's wait for the head of the
+        # panel before an owned one and around the main stream's wait for each panel's tail -- what the first multi-GPU run is judged
+        # on (projected timeline)
         self._timed = os.environ.get("GPX_SHARD_TIMING", "0") not in ("", "0")
-        self._pairs = {"chol_panel_ms": [], "exposed_wait_ms": []}
+        self._pairs = {"chol_panel_ms": [], "chol_panel_rows_ms": [], "exposed_head_wait_ms": [], "exposed_wait_ms": []}
         self.timing = {}
 
     def _mark(self, stream):
         ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def _event(self, stream):
+        ev = self.torch.cuda.Event()
         ev.record(stream)
         return ev
 
@@ -311,23 +358,36 @@ class GpxOps(object):
         return b0, b1, b0 * TILE, (b1 - b0) * TILE, self.layout.npad - b0 * TILE     # blocks, first column, width, rows
 
     def _slot(self, p):
-        return self.stage[p % 2][:self.layout.message_elems(p)]
+        return self.stage[p % NSLOTS][:self.layout.message_elems(p)]
 
-    def _split(self, p, buf):
+    def _views(self, p):
+        """(rows below the square [below, w], square [w, w], inverted diagonal blocks, diagonal) of panel p's message buffer"""
         b0, b1, c0, w, rows = self._geom(p)
-        a = rows * w
-        b = a + (b1 - b0) * TILE * TILE
-        return buf[:a].view(rows, w), buf[a:b].view(b1 - b0, TILE, TILE), buf[b:b + w]
+        buf = self._slot(p)
+        a = (rows - w) * w
+        b = a + w * w
+        c = b + (b1 - b0) * TILE * TILE
+        return buf[:a].view(rows - w, w), buf[a:b].view(w, w), buf[b:c].view(b1 - b0, TILE, TILE), buf[c:c + w]
 
-    def comm_stream_context(self):
-        """the stream every broadcast is posted from: the side stream -- on the owner the message is packed there, elsewhere
-        the receive is ordered there behind the last readers of its buffer (recv_buffer) and overlaps with the main
-        stream's trailing updates"""
-        return self.torch.cuda.stream(self.side)
+    def _part_stream(self, part):
+        return self.head if part == "head" else self.far
+
+    def comm_stream_context(self, part="tail"):
+        """the stream a part's broadcast is posted from: on the owner the part is packed there, elsewhere the receive is ordered
+        there behind the last readers of its buffer; either way it overlaps with the main stream's trailing updates"""
+        return self.torch.cuda.stream(self._part_stream(part))
+
+    def _streams(self):
+        return (self.side, self.head, self.far, self.copy, self.main)
 
     def sync_for_host(self):
-        self.side.synchronize()
-        self.main.synchronize()
+        for st in self._streams():
+            st.synchronize()
+
+    def _wait_slot_free(self, p, stream):
+        """`stream` waits for every read of the message that lived in panel p's slot before"""
+        for ev in self._readers.get(p - NSLOTS, ()):
+            stream.wait_event(ev)
 
     # ---- the ops interface ----------------------------------------------------------------------
     def build_panel(self, p):
@@ -356,68 +416,116 @@ class GpxOps(object):
 
     def factor_panel(self, p, prev):
         b0, b1, c0, w, rows = self._geom(p)
-        torch = self.torch
-        with torch.cuda.stream(self.side):
-            if prev is not None:
-                self.side.wait_event(self._ev_avail[prev])        # panel `prev` has arrived
-            t0 = self._mark(self.side) if self._timed else None
-            if prev is not None:
-                # update with `prev` + factorisation in one native call: square first (the chain starts at once), the rows
-                # below on the library's side stream ahead of their column solves
-                ptr, ldp, first = self._operand[prev]
-                _pb0, _pb1, _pc0, wp, _prows = self._geom(prev)
-                st = self.lib.gpx_dev_chol_panel_next(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1,
-                                                      ctypes.c_void_p(ptr + 8 * (c0 - first) * ldp), ldp, wp, self._p(self.Dinv),
-                                                      self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
-            else:
-                self.side.wait_stream(self.main)                  # the panel has been assembled on the main stream
-                st = self.lib.gpx_dev_chol_panel(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, self._p(self.Dinv),
-                                                 self._p(self.diag), self._p(self.info), self._stream_ptr(self.side))
-            self._gpx.check(st, "gpx_dev_chol_panel(%d)" % p)
-            if self._timed:
-                self._pairs["chol_panel_ms"].append((t0, self._mark(self.side)))
-            buf = self._slot(p)
-            if self.layout.world > 1:
-                # pack: the slot's previous panel (p - 2) must have been read by the main stream's updates
-                if p - 2 in self._ev_main_done:
-                    self.side.wait_event(self._ev_main_done[p - 2])
-                panel, dinv, diag = self._split(p, buf)
-                panel.copy_(self.L[c0:, c0:c0 + w])
+        hr = self.layout.head_rows(p)
+        rowstreams = (self.head, self.far)
+        if prev is not None:
+            # the chain needs the HEAD of `prev` (this panel's square rows of it) and the main stream's earlier updates of this
+            # panel; the rows below the square need prev's TAIL as well
+            self.side.wait_event(self._ev_head[prev])
+            for st in rowstreams:
+                st.wait_event(self._ev_tail[prev])
+            la = self._ev_lookahead.pop(p, None)
+            if la is not None:
+                for st in (self.side,) + rowstreams:
+                    st.wait_event(la)
+        else:
+            self.side.wait_stream(self.main)                      # the panel has been assembled on the main stream
+        t0 = self._mark(self.side) if self._timed else None
+        if prev is not None:
+            ptr, ldp, first = self._operand[prev]
+            _pb0, _pb1, _pc0, wp, _prows = self._geom(prev)
+            P = ctypes.c_void_p(ptr + 8 * (c0 - first) * ldp)
+        else:
+            P, ldp, wp = None, 0, 0
+        # update with `prev` + factorisation in one native call: square first (the chain starts at once), the rows below on
+        # their own streams ahead of their column solves -- the next panel's square rows apart from the rest
+        st = self.lib.gpx_dev_chol_panel_split(self._p(self.L), self.layout.npad, self.layout.nblk, b0, b1, hr // TILE, P, ldp, wp,
+                                               self._p(self.Dinv), self._p(self.diag), self._p(self.info), self._stream_ptr(self.side),
+                                               self._stream_ptr(self.head), self._stream_ptr(self.far))
+        self._gpx.check(st, "gpx_dev_chol_panel_split(%d)" % p)
+        chain_done = self._event(self.side)
+        if self._timed:
+            self._pairs["chol_panel_ms"].append((t0, self._mark(self.side)))
+            self.far.wait_event(chain_done)
+            self.far.wait_stream(self.head)
+            self._pairs["chol_panel_rows_ms"].append((t0, self._mark(self.far)))
+        if prev is not None:                                      # the step's reads of prev's message buffer
+            self._readers.setdefault(prev, []).extend(self._event(st) for st in (self.side,) + rowstreams)
+        if self.layout.world > 1:
+            lower, square, dinv, diag = self._views(p)
+            below = rows - w
+            for st in rowstreams:
+                self._wait_slot_free(p, st)
+            if hr > 0:
+                with self.torch.cuda.stream(self.head):
+                    lower[:hr].copy_(self.L[c0 + w:c0 + w + hr, c0:c0 + w])
+            with self.torch.cuda.stream(self.far):
+                self.far.wait_event(chain_done)                   # square, inverted blocks and diagonal are the chain's
+                if below > hr:
+                    lower[hr:].copy_(self.L[c0 + w + hr:, c0:c0 + w])
+                square.copy_(self.L[c0:c0 + w, c0:c0 + w])
                 dinv.copy_(self.Dinv[b0:b1])
                 diag.copy_(self.diag[c0:c0 + w])
+        else:
+            self.far.wait_event(chain_done)
         # the owner's own updates read the panel in place
-        self._operand[p] = (self.L.data_ptr() + 8 * (c0 * self.layout.npad + c0), self.layout.npad, c0)
-        return buf
+        self._operand[p] = (self.L.data_ptr() + 8 * ((c0 + w) * self.layout.npad + c0), self.layout.npad, c0 + w)
 
-    def recv_buffer(self, p):
-        # the receive is posted from the side stream: behind the side stream's own reads of this slot (copy of panel p - 2
-        # into L, update of an owned panel p - 1 with it) and, through the event, behind the main stream's updates with it
-        if p - 2 in self._ev_main_done:
-            self.side.wait_event(self._ev_main_done[p - 2])
-        return self._slot(p)
+    def message(self, p, part):
+        lo, hi = self.layout.part_range(p, part)
+        if self.layout.owner(p) != self.rank:
+            # the receive is posted from the part's stream: behind every read of the slot's previous tenant
+            self._wait_slot_free(p, self._part_stream(part))
+        return self._slot(p)[lo:hi]
 
-    def adopt_panel(self, p, buf, work):
+    def adopt(self, p, part, buf, work):
         torch = self.torch
         b0, b1, c0, w, rows = self._geom(p)
+        hr = self.layout.head_rows(p)
+        own = self.layout.owner(p) == self.rank
+        lower, square, dinv, diag = self._views(p)
+        if part == "head":
+            # the chain stream waits for the head -- exposed only where this rank owns the next panel
+            with torch.cuda.stream(self.side):
+                t0 = self._mark(self.side) if self._timed and self.layout.owner(p + 1) == self.rank else None
+                work.wait()
+                if own:
+                    self.side.wait_stream(self.head)              # the head rows' solves (and their pack)
+                if t0 is not None:
+                    self._pairs["exposed_head_wait_ms"].append((t0, self._mark(self.side)))
+                ev = self._event(self.side)
+            self._ev_head[p] = ev
+            if not own:
+                with torch.cuda.stream(self.copy):
+                    self.copy.wait_event(ev)
+                    self.L[c0 + w:c0 + w + hr, c0:c0 + w].copy_(lower[:hr])
+                    self._readers.setdefault(p, []).append(self._event(self.copy))
+            return
+        with torch.cuda.stream(self.far):
+            work.wait()                                           # (owner: the far rows' solves and the pack are on this stream)
+            ev = self._event(self.far)
+        self._ev_tail[p] = ev
+        if hr == 0:
+            self._ev_head[p] = ev
         with torch.cuda.stream(self.main):
             t0 = self._mark(self.main) if self._timed else None
-            work.wait()                                           # main stream waits for the message (no host block on RCCL)
-            if self.layout.owner(p) == self.rank:
-                self.main.wait_stream(self.side)                  # factorisation (and pack) of the own panel
+            self.main.wait_event(ev)                              # no host block on RCCL
+            self.main.wait_event(self._ev_head[p])
             if self._timed:                                       # main-stream idle time in front of panel p's updates
                 self._pairs["exposed_wait_ms"].append((t0, self._mark(self.main)))
-            ev = torch.cuda.Event()
-            ev.record(self.main)
-        self._ev_avail[p] = ev
-        if self.layout.owner(p) != self.rank:
-            panel, dinv, diag = self._split(p, buf)
-            self._operand[p] = (panel.data_ptr(), w, c0)
-            # copy into this rank's L / Dinv / diag on the side stream: needed for the complete factor only
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(ev)
-                self.L[c0:, c0:c0 + w].copy_(panel)
+        if not own:
+            self._operand[p] = (lower.data_ptr(), w, c0 + w)
+            # copy into this rank's L / Dinv / diag: needed for the complete factor only
+            with torch.cuda.stream(self.copy):
+                self.copy.wait_event(ev)
+                if rows - w > hr:
+                    self.L[c0 + w + hr:, c0:c0 + w].copy_(lower[hr:])
+                self.L[c0:c0 + w, c0:c0 + w].copy_(square)
                 self.Dinv[b0:b1].copy_(dinv)
                 self.diag[c0:c0 + w].copy_(diag)
+                self._readers.setdefault(p, []).append(self._event(self.copy))
+        for d_ in (self._ev_head, self._ev_tail, self._readers):
+            d_.pop(p - NSLOTS - 1, None)
 
     def update_panels(self, qs, p):
         # consecutive owned panels form one launch (world size 1: all of them = the single bulk SYRK of csrc/chol.hip)
@@ -428,17 +536,18 @@ class GpxOps(object):
                 runs[-1][1] = c0 + w
             else:
                 runs.append([c0, c0 + w])
-        for q0, q1 in runs:
+        for i, (q0, q1) in enumerate(runs):
             self._gemm(q0, q1, p, self.main)
-        ev = self.torch.cuda.Event()
-        ev.record(self.main)
-        self._ev_main_done[p] = ev
-        self._ev_main_done.pop(p - 3, None)
+            if i == 0 and qs[0] == p + 2:
+                # panel p + 2 now lacks panel p + 1 only: its owner's chain waits for THIS, not for the rest of the step's updates
+                self._ev_lookahead[p + 2] = self._event(self.main)
+        if runs:
+            self._readers.setdefault(p, []).append(self._event(self.main))
         self._operand.pop(p - 2, None)
 
     def finish(self):
-        self.side.synchronize()
-        self.main.synchronize()
+        for st in self._streams():
+            st.synchronize()
         if self._timed:
             self.timing = {k: float(sum(a.elapsed_time(b) for a, b in v)) for k, v in self._pairs.items()}
             self.timing["panels_owned"] = len(self._pairs["chol_panel_ms"])
@@ -491,7 +600,7 @@ class ShardedGaussianProcess(object):
     """GaussianProcess over R GPUs: sharded K-build + panel-broadcast Cholesky, query-sharded estimate_many.
     Must be constructed collectively by every rank of `group` with identical (x, t, theta)."""
 
-    def __init__(self, x, t, theta_min, group=None, device=None, comm=None):
+    def __init__(self, x, t, theta_min, group=None, device=None, comm=None, split=None):
         import torch
         import torch.distributed as dist
         from . import _gpx
@@ -510,7 +619,7 @@ class ShardedGaussianProcess(object):
         self.theta_min = np.ascontiguousarray(theta_min, dtype=np.float64)
         self._x_dev = torch.as_tensor(_gpx.f64(x)).to(self.device)
         self._t_dev = torch.as_tensor(_gpx.f64(self.t)).to(self.device)
-        self.layout = PanelLayout(self.n, self.world)
+        self.layout = PanelLayout(self.n, self.world, split=split)
         self._comm = comm if comm is not None else TorchComm(group)
         self._ops = None
         self._h = ctypes.c_void_p()
@@ -795,7 +904,7 @@ def bench_main(args):
     rearm()
     dist.barrier()
     # per-rank owner-side panel time and exposed message waits of the timed fits (ms per step), gathered on rank 0
-    keys = ["chol_panel_ms", "exposed_wait_ms", "panels_owned"]
+    keys = ["chol_panel_ms", "chol_panel_rows_ms", "exposed_head_wait_ms", "exposed_wait_ms", "panels_owned"]
     mine_t = torch.tensor([shard_ms.get(k_, 0.0) / max(1, args.steps) for k_ in keys], dtype=torch.float64, device=dev)
     all_t = [torch.zeros_like(mine_t) for _ in range(world)]
     dist.all_gather(all_t, mine_t)
@@ -816,7 +925,9 @@ def bench_main(args):
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "%s: N=%d d=%d M=%d, column panels of K (1024 wide) block-cyclic over %d GPUs, "
-                                   "RCCL panel broadcast, query-sharded estimate_many" % ((args.workload or "c4").upper(), N, d, M, world),
+                                   "RCCL panel broadcast (%s), query-sharded estimate_many" % (
+                                       (args.workload or "c4").upper(), N, d, M, world,
+                                       "head + tail per panel" if gp.layout.split else "one message per panel"),
                        "global_batch": N + M, "parallelism": "panel-sharded x%d" % world},
             "fit_ms": tf / args.steps * 1e3,
             "predict_ms": tp / args.steps * 1e3,

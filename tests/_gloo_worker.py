@@ -22,7 +22,7 @@ class CpuOps(object):
     def __init__(self, x, theta, layout, rank):
         self.layout, self.x, self.theta, self.rank = layout, x, theta, rank
         npad = layout.npad
-        self.stage = [torch.empty(npad * layout.pb * TILE, dtype=torch.float64) for _ in range(2)]   # two message slots
+        self.stage = [torch.empty(layout.message_elems(0), dtype=torch.float64) for _ in range(3)]     # message slots
         self.L = torch.full((npad, npad), float("nan"), dtype=torch.float64)   # NaN: unbuilt regions must never be read
         self.calls = []
 
@@ -56,9 +56,14 @@ class CpuOps(object):
         if c1 < self.layout.npad:
             self.L[c1:, c0:c1] = torch.linalg.solve_triangular(D, self.L[c1:, c0:c1].T, upper=False).T
         self.calls.append(("factor", p))
-        buf = self.stage[p % 2][:self._view(p).numel()]
-        buf.copy_(self._view(p).reshape(-1))
-        return buf
+        # the message: rows below the square | the square (the product packs inverted blocks and the diagonal behind it)
+        buf = self._slot(p)
+        buf.fill_(float("nan"))
+        w = c1 - c0
+        nlow = (self.layout.npad - c1) * w
+        buf[:nlow].copy_(self.L[c1:, c0:c1].reshape(-1))
+        buf[nlow:nlow + w * w].copy_(D.reshape(-1))
+        buf[nlow + w * w:].zero_()
 
     def _update(self, q, p):
         pb0, pb1 = self.layout.blocks(p)
@@ -74,17 +79,31 @@ class CpuOps(object):
         for q in qs:
             self._update(q, p)
 
-    def _view(self, p):
-        b0, b1 = self.layout.blocks(p)
-        return self.L[b0 * TILE:, b0 * TILE:b1 * TILE]
+    def _slot(self, p):
+        return self.stage[p % len(self.stage)][:self.layout.message_elems(p)]
 
-    def recv_buffer(self, p):
-        return self.stage[p % 2][:self._view(p).numel()]
+    def message(self, p, part):
+        lo, hi = self.layout.part_range(p, part)
+        assert hi > lo and part in self.layout.parts(p)
+        self.calls.append(("message", p, part))
+        return self._slot(p)[lo:hi]
 
-    def adopt_panel(self, p, buf, work):
+    def adopt(self, p, part, buf, work):
         work.wait()
-        if self.layout.owner(p) != self.rank:
-            self._view(p).copy_(buf.view(self._view(p).shape))
+        self.calls.append(("adopt", p, part))
+        if self.layout.owner(p) == self.rank:
+            return
+        b0, b1 = self.layout.blocks(p)
+        c0, c1 = b0 * TILE, b1 * TILE
+        w, hr = c1 - c0, self.layout.head_rows(p)
+        if part == "head":
+            assert buf.numel() == hr * w
+            self.L[c1:c1 + hr, c0:c1] = buf.view(hr, w)
+        else:
+            below = self.layout.npad - c1
+            rest = buf[:(below - hr) * w].view(below - hr, w)
+            self.L[c1 + hr:, c0:c1] = rest
+            self.L[c0:c1, c0:c1] = buf[(below - hr) * w:(below - hr) * w + w * w].view(w, w)
 
     def finish(self):
         return 0
@@ -97,10 +116,11 @@ def main():
     rng = np.random.RandomState(11)
     x = rng.uniform(0, 5, (n, d))
     theta = np.log(np.array([1.5, 0.05, 0.3, 0.2, 0.4]))
-    layout = PanelLayout(n, world, panel_blocks=pb)
+    mode = sys.argv[3] if len(sys.argv) > 3 else "bcast"
+    layout = PanelLayout(n, world, panel_blocks=pb, split=not mode.endswith("-whole"))
     ops = CpuOps(x, theta, layout, rank)
     # split_bytes=1: every message whose length the world size divides travels as scatter + all-gather
-    info = panel_cholesky(ops, layout, rank, TorchComm(split_bytes=1 if len(sys.argv) > 3 and sys.argv[3] == "split" else 1 << 40))
+    info = panel_cholesky(ops, layout, rank, TorchComm(split_bytes=1 if mode.startswith("split") else 1 << 40))
     assert info == 0
     with np.errstate(divide="ignore"):
         K = orc.gram(x, theta)
@@ -114,6 +134,11 @@ def main():
     for c in ops.calls:
         if c[0] == "update":
             assert layout.owner(c[1]) == rank and c[2] < c[1]
+    # every panel's parts are posted and adopted by every rank in the same order: head (the next square's rows) before tail
+    want = [(p, part) for p in range(layout.npanels) for part in layout.parts(p)]
+    assert [c[1:] for c in ops.calls if c[0] == "message"] == want and [c[1:] for c in ops.calls if c[0] == "adopt"] == want
+    if layout.split and layout.npanels > 1:
+        assert ("head" in layout.parts(0)) and layout.parts(layout.npanels - 1) == ("tail",)
     nupd = sum(1 for c in ops.calls if c[0] == "update")
     assert nupd == sum(q for q in layout.owned(rank)), (nupd, layout.owned(rank))   # every earlier panel exactly once
     ok = torch.tensor([1.0 if err < 1e-10 else 0.0])

@@ -32,6 +32,8 @@ def main():
     mean, var = gp.estimate_many(xs)
     ok = True
     if rank == 0:
+        print("panel message: %s" % ("head + tail" if gp.layout.split else "whole"))
+    if rank == 0:
         ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
         m1, v1 = ref.estimate_many(xs)
         e1 = max(np.abs(mean - m1).max(), np.abs(var - v1).max())

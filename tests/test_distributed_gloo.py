@@ -8,11 +8,14 @@ import pytest
 from conftest import ROOT
 
 
-@pytest.mark.parametrize("n,pb,world,mode", [(700, 1, 2, "bcast"), (1000, 2, 2, "split"), (390, 1, 3, "split"), (900, 1, 2, "split")])
+@pytest.mark.parametrize("n,pb,world,mode", [(700, 1, 2, "bcast"), (1000, 2, 2, "split"), (390, 1, 3, "split"), (900, 1, 2, "split"),
+                                             (1000, 2, 2, "split-whole"), (390, 1, 3, "bcast-whole")])
 def test_panel_cholesky_gloo(n, pb, world, mode):
+    """mode: transport ("bcast" one broadcast per message part, "split" scatter + all-gather) and, with "-whole", one message per panel
+    instead of head (the next panel's square rows) + tail"""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29600 + n % 97),
+           "--master-addr", "127.0.0.1", "--master-port", str(29600 + (n + 31 * len(mode)) % 97),
            os.path.join(ROOT, "tests", "_gloo_worker.py"), str(n), str(pb), mode]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

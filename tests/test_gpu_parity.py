@@ -527,21 +527,88 @@ def test_c4_full_size_properties():
     _gpx.lib.gpx_pool_trim()
 
 
+def test_chol_panel_split_is_the_joined_step_on_caller_streams():
+    """gpx_dev_chol_panel_split -- the multi-GPU owner's panel step with the rows below the square cut into the next panel's square
+    rows (stream_head) and the rest (stream_far) -- against numpy's factor and, bit for bit, against gpx_dev_chol_panel_next (one slice,
+    joined): a middle panel with a previous panel to apply (launch-per-step chain), head = all / some / none of the rows below, and the
+    first panel (square launch of the dataflow kernel, no previous panel); argument checks.  Multi-GPU form of Covariance.py:179."""
+    nblk = 21
+    n = 128 * nblk
+    rng = np.random.RandomState(77)
+    B = rng.randn(n, 64)
+    A = B.dot(B.T) / 64.0 + np.diag(rng.uniform(1.0, 2.0, n))
+    ref = np.linalg.cholesky(A)
+    dev = torch.device("cuda")
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sp = lambda st: ctypes.c_void_p(st.cuda_stream)  # noqa: E731
+
+    def step(b0, b1, hb, split):
+        c0 = 128 * b0
+        M = A.copy()
+        M[:, :c0] = ref[:, :c0]
+        if b0 >= 8:     # every panel but the one before [b0, b1) applied; that one is handed over as `prev`
+            k0 = c0 - 1024
+            M[c0:, c0:] = A[c0:, c0:] - ref[c0:, :k0].dot(ref[c0:, :k0].T)
+            prev = torch.as_tensor(np.ascontiguousarray(ref[c0:, k0:c0])).to(dev)
+        else:
+            prev = None
+        Ld = torch.as_tensor(M).to(dev).contiguous()
+        dinv = torch.zeros((nblk, 128, 128), dtype=torch.float64, device=dev)
+        diag = torch.zeros(n, dtype=torch.float64, device=dev)
+        info = torch.zeros(1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        if split:
+            st = _gpx.lib.gpx_dev_chol_panel_split(_p(Ld), n, nblk, b0, b1, hb, _p(prev) if prev is not None else None, 1024, 1024,
+                                                   _p(dinv), _p(diag), _p(info), sp(streams[0]), sp(streams[1]), sp(streams[2]))
+        elif prev is not None:
+            st = _gpx.lib.gpx_dev_chol_panel_next(_p(Ld), n, nblk, b0, b1, _p(prev), 1024, 1024, _p(dinv), _p(diag), _p(info), sp(streams[0]))
+        else:
+            st = _gpx.lib.gpx_dev_chol_panel(_p(Ld), n, nblk, b0, b1, _p(dinv), _p(diag), _p(info), sp(streams[0]))
+        _gpx.check(st, "panel step")
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        return Ld.cpu().numpy(), dinv.cpu().numpy(), diag.cpu().numpy()
+
+    for b0, b1 in ((8, 16), (0, 8)):
+        c0, c1 = 128 * b0, 128 * b1
+        base = step(b0, b1, 0, False)
+        np.testing.assert_allclose(np.tril(base[0][c0:c1, c0:c1]), ref[c0:c1, c0:c1], rtol=0, atol=1e-12 * np.abs(ref).max())
+        np.testing.assert_allclose(base[0][c1:, c0:c1], ref[c1:, c0:c1], rtol=0, atol=1e-12 * np.abs(ref).max())
+        for hb in (0, 2, 5, 8, 40):
+            got = step(b0, b1, hb, True)
+            np.testing.assert_array_equal(got[0][c0:, c0:c1], base[0][c0:, c0:c1])
+            np.testing.assert_array_equal(got[1][b0:b1], base[1][b0:b1])
+            np.testing.assert_array_equal(got[2][c0:c1], base[2][c0:c1])
+            np.testing.assert_array_equal(got[0][c0:, c1:], base[0][c0:, c1:])          # nothing right of the panel is touched
+    # last panel: no rows below at all
+    last = step(16, 21, 8, True)
+    np.testing.assert_allclose(np.tril(last[0][2048:, 2048:]), ref[2048:, 2048:], rtol=0, atol=1e-12 * np.abs(ref).max())
+    # argument checks: the row streams must be two distinct non-null streams other than `stream`
+    z = torch.zeros(16, dtype=torch.float64, device=dev)
+    zi = torch.zeros(1, dtype=torch.int32, device=dev)
+    for a_, b_, c_ in ((streams[0], streams[0], streams[2]), (streams[0], streams[1], streams[1])):
+        assert _gpx.lib.gpx_dev_chol_panel_split(_p(z), 128, 1, 0, 1, 0, None, 0, 0, _p(z), _p(z), _p(zi), sp(a_), sp(b_), sp(c_)) == -1
+    assert _gpx.lib.gpx_dev_chol_panel_split(_p(z), 128, 1, 0, 1, 0, None, 0, 0, _p(z), _p(z), _p(zi), sp(streams[0]), None, sp(streams[2])) == -1
+
+
 # ------------------------------------------------------------------------------------------------
 # N > 1 code path on the one GPU of the test box: 2 ranks share cuda:0, panels travel over gloo (host staged)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,d", [(2500, 4), (8200, 6)])      # 8200 rows = 65 blocks = 9 outer panels
-def test_sharded_fit_two_ranks_share_one_gpu(N, d):
+@pytest.mark.parametrize("N,d,message", [(2500, 4, "split"), (8200, 6, "split"), (8200, 6, "whole")])      # 8200 rows = 65 blocks = 9 outer panels
+def test_sharded_fit_two_ranks_share_one_gpu(N, d, message):
+    """panel messages in two parts (head = the next panel's square rows, then the tail; the default for more than one rank) and as one
+    message per panel"""
     import os
     import subprocess
     import sys
     from conftest import ROOT
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", GPX_PANEL_MESSAGE=message)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29733", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(N), str(d)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded vs single-GPU" in r.stdout
+    assert ("panel message: head + tail" if message == "split" else "panel message: whole") in r.stdout
 
 
 def test_sharded_fit_four_ranks_share_one_gpu_c3_size():
@@ -557,7 +624,7 @@ def test_sharded_fit_four_ranks_share_one_gpu_c3_size():
            "--master-port", "29737", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), "16384", "8", "light"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "sharded vs single-GPU" in r.stdout and "4 ranks, 16 panels" in r.stdout
+    assert "sharded vs single-GPU" in r.stdout and "4 ranks, 16 panels" in r.stdout and "panel message: head + tail" in r.stdout
 
 
 def test_sharded_fit_c4_size_on_rccl_world_size_one():
@@ -668,11 +735,14 @@ gp.close()
 # the panel transport's collectives (scatter + all_gather_into_tensor, and the plain broadcast) accepted by RCCL: a group of one
 # rank normally skips them
 from skgpuppy_amd.distributed import TorchComm
+# ... for the message in two parts (head, tail: the default above one rank) and in one
 for comm in (TorchComm(split_bytes=1, exercise_single_rank=True), TorchComm(split_bytes=1 << 60, exercise_single_rank=True)):
-    g2 = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=comm)
-    m2, v2 = g2.estimate_many(xs)
-    assert np.abs(m2 - m1).max() < 1e-10 and np.abs(v2 - v1).max() < 1e-10 and comm._split_ok
-    g2.close()
+    for split in (True, False):
+        g2 = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=comm, split=split)
+        assert g2.layout.parts(0) == (("head", "tail") if split else ("tail",))
+        m2, v2 = g2.estimate_many(xs)
+        assert np.abs(m2 - m1).max() < 1e-10 and np.abs(v2 - v1).max() < 1e-10 and comm._split_ok
+        g2.close()
 # a tight cluster with vt = 0: K is numerically indefinite -> the single-GPU fit takes the +1e-5 jitter, and so must the sharded one
 xd = rng.uniform(0, 1e-4, (600, d)); td = rng.randn(600); xs = rng.uniform(0, 1e-4, (77, d))
 th2 = np.array([0.0, -np.inf] + [0.0] * d)
