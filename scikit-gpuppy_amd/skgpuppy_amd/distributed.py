@@ -324,6 +324,7 @@ class GpxOps(object):
         self._ev_tail = {}                              # panel -> event: the whole message is there
         self._ev_lookahead = {}                         # panel -> event: the main stream has applied every panel but the last one to it
         self._readers = {}                              # panel -> events behind every read of its message buffer
+        self._local = {}                                # (own panel, part) -> event: that part's rows are solved (before pack and send)
         # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's chain (side stream; chol_panel_ms), from the chain's start to the
         # last row's solve (far stream; chol_panel_rows_ms = the whole panel step), around the side stream's wait for the head of the
         # panel before an owned one and around the main stream's wait for each panel's tail -- what the first multi-GPU run is judged
@@ -444,11 +445,17 @@ class GpxOps(object):
                                                self._stream_ptr(self.head), self._stream_ptr(self.far))
         self._gpx.check(st, "gpx_dev_chol_panel_split(%d)" % p)
         chain_done = self._event(self.side)
+        self.far.wait_event(chain_done)
+        # what this rank's own streams wait for: the solves, not the broadcasts
+        if hr > 0:
+            self._local[(p, "head")] = self._event(self.head)
+        self._local[(p, "tail")] = self._event(self.far)
         if self._timed:
             self._pairs["chol_panel_ms"].append((t0, self._mark(self.side)))
-            self.far.wait_event(chain_done)
-            self.far.wait_stream(self.head)
-            self._pairs["chol_panel_rows_ms"].append((t0, self._mark(self.far)))
+            with self.torch.cuda.stream(self.copy):               # (a stream that nothing else waits for)
+                for part in self.layout.parts(p):
+                    self.copy.wait_event(self._local[(p, part)])
+                self._pairs["chol_panel_rows_ms"].append((t0, self._mark(self.copy)))
         if prev is not None:                                      # the step's reads of prev's message buffer
             self._readers.setdefault(prev, []).extend(self._event(st) for st in (self.side,) + rowstreams)
         if self.layout.world > 1:
@@ -459,15 +466,12 @@ class GpxOps(object):
             if hr > 0:
                 with self.torch.cuda.stream(self.head):
                     lower[:hr].copy_(self.L[c0 + w:c0 + w + hr, c0:c0 + w])
-            with self.torch.cuda.stream(self.far):
-                self.far.wait_event(chain_done)                   # square, inverted blocks and diagonal are the chain's
+            with self.torch.cuda.stream(self.far):                # (behind the chain: square, inverted blocks and diagonal are its)
                 if below > hr:
                     lower[hr:].copy_(self.L[c0 + w + hr:, c0:c0 + w])
                 square.copy_(self.L[c0:c0 + w, c0:c0 + w])
                 dinv.copy_(self.Dinv[b0:b1])
                 diag.copy_(self.diag[c0:c0 + w])
-        else:
-            self.far.wait_event(chain_done)
         # the owner's own updates read the panel in place
         self._operand[p] = (self.L.data_ptr() + 8 * ((c0 + w) * self.layout.npad + c0), self.layout.npad, c0 + w)
 
@@ -484,16 +488,24 @@ class GpxOps(object):
         hr = self.layout.head_rows(p)
         own = self.layout.owner(p) == self.rank
         lower, square, dinv, diag = self._views(p)
+        if own:
+            # the owner's streams go on as soon as the rows are SOLVED (factor_panel's events); the broadcast is waited for on the copy
+            # stream only, as one more reader of the message buffer
+            ev = self._local.pop((p, part))
+            with torch.cuda.stream(self.copy):
+                work.wait()
+                self._readers.setdefault(p, []).append(self._event(self.copy))
         if part == "head":
             # the chain stream waits for the head -- exposed only where this rank owns the next panel
             with torch.cuda.stream(self.side):
                 t0 = self._mark(self.side) if self._timed and self.layout.owner(p + 1) == self.rank else None
-                work.wait()
                 if own:
-                    self.side.wait_stream(self.head)              # the head rows' solves (and their pack)
+                    self.side.wait_event(ev)
+                else:
+                    work.wait()
+                    ev = self._event(self.side)
                 if t0 is not None:
                     self._pairs["exposed_head_wait_ms"].append((t0, self._mark(self.side)))
-                ev = self._event(self.side)
             self._ev_head[p] = ev
             if not own:
                 with torch.cuda.stream(self.copy):
@@ -501,9 +513,10 @@ class GpxOps(object):
                     self.L[c0 + w:c0 + w + hr, c0:c0 + w].copy_(lower[:hr])
                     self._readers.setdefault(p, []).append(self._event(self.copy))
             return
-        with torch.cuda.stream(self.far):
-            work.wait()                                           # (owner: the far rows' solves and the pack are on this stream)
-            ev = self._event(self.far)
+        if not own:
+            with torch.cuda.stream(self.far):
+                work.wait()
+                ev = self._event(self.far)
         self._ev_tail[p] = ev
         if hr == 0:
             self._ev_head[p] = ev

@@ -10,20 +10,23 @@ from fit_timeline import load, short
 
 def main():
     rows = load(sys.argv[1])
-    # a sharded fit starts with its Gram launches (one per owned panel, on the main stream): the last run of consecutive gram kernels
+    # a sharded fit starts with its Gram launches, one per owned panel back to back on the main stream (predict has a single one per
+    # chunk): the last group of at least four gram kernels less than 2 ms apart
     grams = [i for i, r in enumerate(rows) if "gram" in r[0]]
-    starts = [i for k, i in enumerate(grams) if k == 0 or rows[grams[k - 1]][1] < rows[i][1] - 5e6]   # > 5 ms apart: a new fit
-    i0 = starts[int(sys.argv[2]) if len(sys.argv) > 2 else -1]
+    groups = []
+    for i in grams:
+        if groups and rows[i][1] - rows[groups[-1][-1]][1] < 2e6:
+            groups[-1].append(i)
+        else:
+            groups.append([i])
+    groups = [g for g in groups if len(g) >= 4]
+    grp = groups[int(sys.argv[2]) if len(sys.argv) > 2 else -1]
+    i0 = grp[0]
     t0 = rows[i0][1]
-    fit = [r for r in rows[i0:] if r[1] - t0 < 60e6]
-    # the fit ends where the predict's Gram begins (next gram launch > 5 ms after the first) or the trace ends
-    end = None
-    for r in fit:
-        if "gram" in r[0] and r[1] - t0 > 5e6:
-            end = r[1]
-            break
-    if end is not None:
-        fit = [r for r in fit if r[1] < end]
+    # ... and ends where the next Gram launch (predict's) begins
+    later = [rows[i][1] for i in grams if i > grp[-1]]
+    end = later[0] if later else rows[-1][2] + 1
+    fit = [r for r in rows[i0:] if r[1] < end]
     chain_q = None
     chains = []          # [start, end, kind, steps]
     for r in fit:
@@ -48,8 +51,9 @@ def main():
     print("panel  chain start -> end (us)        kind           rows trailing it on other queues end at (us)      next chain starts")
     for p, c in enumerate(chains):
         nxt = chains[p + 1][0] if p + 1 < len(chains) else None
-        # kernels of the other high-priority queues that start inside [chain start, next chain's end): the row slices of this panel
-        hi = chains[p + 1][1] if p + 1 < len(chains) else fit[-1][2]
+        # kernels of the other queues that start inside [chain start, next chain's start): the row slices of this panel (the slices of
+        # the next panel begin with their update right behind the next square's)
+        hi = chains[p + 1][0] if p + 1 < len(chains) else fit[-1][2]
         ends = {}
         for r in fit:
             if r[3] != chain_q and c[0] <= r[1] < hi and short(r[0]) not in ("LEAF", "SQK") and r[4] * max(1, r[5]) < 1200:
