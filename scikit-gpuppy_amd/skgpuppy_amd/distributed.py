@@ -325,8 +325,8 @@ class GpxOps(object):
         self._ev_lookahead = {}                         # panel -> event: the main stream has applied every panel but the last one to it
         self._readers = {}                              # panel -> events behind every read of its message buffer
         self._local = {}                                # (own panel, part) -> event: that part's rows are solved (before pack and send)
-        # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's chain (side stream; chol_panel_ms), from the chain's start to the
-        # last row's solve (far stream; chol_panel_rows_ms = the whole panel step), around the side stream's wait for the head of the
+        # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's chain (side stream; chol_panel_ms), from the point where the far
+        # rows may start to the last row's solve (chol_panel_rows_ms = the whole panel step), around the side stream's wait for the head of the
         # panel before an owned one and around the main stream's wait for each panel's tail -- what the first multi-GPU run is judged
         # on (projected timeline)
         self._timed = os.environ.get("GPX_SHARD_TIMING", "0") not in ("", "0")
@@ -432,6 +432,7 @@ class GpxOps(object):
         else:
             self.side.wait_stream(self.main)                      # the panel has been assembled on the main stream
         t0 = self._mark(self.side) if self._timed else None
+        t0_rows = self._mark(self.far) if self._timed else None   # (behind the far rows' own gates: the tail of `prev`, the look-ahead update)
         if prev is not None:
             ptr, ldp, first = self._operand[prev]
             _pb0, _pb1, _pc0, wp, _prows = self._geom(prev)
@@ -455,7 +456,7 @@ class GpxOps(object):
             with self.torch.cuda.stream(self.copy):               # (a stream that nothing else waits for)
                 for part in self.layout.parts(p):
                     self.copy.wait_event(self._local[(p, part)])
-                self._pairs["chol_panel_rows_ms"].append((t0, self._mark(self.copy)))
+                self._pairs["chol_panel_rows_ms"].append((t0_rows, self._mark(self.copy)))
         if prev is not None:                                      # the step's reads of prev's message buffer
             self._readers.setdefault(prev, []).extend(self._event(st) for st in (self.side,) + rowstreams)
         if self.layout.world > 1:
