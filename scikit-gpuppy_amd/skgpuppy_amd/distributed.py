@@ -332,6 +332,16 @@ class GpxOps(object):
         self._timed = os.environ.get("GPX_SHARD_TIMING", "0") not in ("", "0")
         self._pairs = {"chol_panel_ms": [], "chol_panel_rows_ms": [], "exposed_head_wait_ms": [], "exposed_wait_ms": []}
         self.timing = {}
+        # GPX_SHARD_CHAOS=<seed> (tests): random busy-waits of up to ~1 ms on randomly chosen streams in front of the schedule's steps -- a
+        # stream that runs late must never change the result; a missing event edge would
+        chaos = os.environ.get("GPX_SHARD_CHAOS", "")
+        self._chaos = np.random.RandomState(int(chaos) + 1000 * rank) if chaos not in ("", "0") else None
+
+    def _shake(self):
+        if self._chaos is not None and self._chaos.rand() < 0.4:
+            st = self._streams()[self._chaos.randint(5)]
+            with self.torch.cuda.stream(st):
+                self.torch.cuda._sleep(int(self._chaos.randint(100000, 2500000)))
 
     def _mark(self, stream):
         ev = self.torch.cuda.Event(enable_timing=True)
@@ -419,6 +429,7 @@ class GpxOps(object):
         b0, b1, c0, w, rows = self._geom(p)
         hr = self.layout.head_rows(p)
         rowstreams = (self.head, self.far)
+        self._shake()
         if prev is not None:
             # the chain needs the HEAD of `prev` (this panel's square rows of it) and the main stream's earlier updates of this
             # panel; the rows below the square need prev's TAIL as well
@@ -477,6 +488,7 @@ class GpxOps(object):
         self._operand[p] = (self.L.data_ptr() + 8 * ((c0 + w) * self.layout.npad + c0), self.layout.npad, c0 + w)
 
     def message(self, p, part):
+        self._shake()
         lo, hi = self.layout.part_range(p, part)
         if self.layout.owner(p) != self.rank:
             # the receive is posted from the part's stream: behind every read of the slot's previous tenant
@@ -485,6 +497,7 @@ class GpxOps(object):
 
     def adopt(self, p, part, buf, work):
         torch = self.torch
+        self._shake()
         b0, b1, c0, w, rows = self._geom(p)
         hr = self.layout.head_rows(p)
         own = self.layout.owner(p) == self.rank
@@ -542,6 +555,7 @@ class GpxOps(object):
             d_.pop(p - NSLOTS - 1, None)
 
     def update_panels(self, qs, p):
+        self._shake()
         # consecutive owned panels form one launch (world size 1: all of them = the single bulk SYRK of csrc/chol.hip)
         runs = []
         for q in qs:

@@ -12,7 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "scikit-gpuppy_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 import skgpuppy_amd as sk  # noqa: E402
-from skgpuppy_amd.distributed import HostStagedComm, ShardedGaussianProcess  # noqa: E402
+from skgpuppy_amd.distributed import HostStagedComm, ShardedGaussianProcess, TorchComm  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -28,11 +28,16 @@ def main():
     xs = rng.uniform(0, 10, (M, d))
     theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
     torch.cuda.set_device(0)
-    gp = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=HostStagedComm())
+    # transport: "host" (default) = broadcasts staged through the host with every stream synchronised around them; "gloo-device" = the product's
+    # TorchComm on a gloo group with DEVICE tensors -- gloo orders itself against the posting stream by events, like RCCL, so the schedule's own
+    # event edges (buffer reuse, head before tail, copies into L) are what keeps the ranks correct
+    transport = sys.argv[4] if len(sys.argv) > 4 else "host"
+    comm = HostStagedComm() if transport == "host" else TorchComm()
+    gp = ShardedGaussianProcess(x, t, theta, device=torch.device("cuda", 0), comm=comm)
     mean, var = gp.estimate_many(xs)
     ok = True
     if rank == 0:
-        print("panel message: %s" % ("head + tail" if gp.layout.split else "whole"))
+        print("panel message: %s, transport: %s" % ("head + tail" if gp.layout.split else "whole", transport))
     if rank == 0:
         ref = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
         m1, v1 = ref.estimate_many(xs)

@@ -594,34 +594,41 @@ def test_chol_panel_split_is_the_joined_step_on_caller_streams():
 # ------------------------------------------------------------------------------------------------
 # N > 1 code path on the one GPU of the test box: 2 ranks share cuda:0, panels travel over gloo (host staged)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("N,d,message", [(2500, 4, "split"), (8200, 6, "split"), (8200, 6, "whole")])      # 8200 rows = 65 blocks = 9 outer panels
-def test_sharded_fit_two_ranks_share_one_gpu(N, d, message):
+@pytest.mark.parametrize("N,d,message,transport", [(2500, 4, "split", "host"), (8200, 6, "split", "host"), (8200, 6, "whole", "host"),
+                                                   (8200, 6, "split", "gloo-device"), (8200, 6, "whole", "gloo-device")])      # 8200 rows = 65 blocks = 9 outer panels
+def test_sharded_fit_two_ranks_share_one_gpu(N, d, message, transport):
     """panel messages in two parts (head = the next panel's square rows, then the tail; the default for more than one rank) and as one
-    message per panel"""
+    message per panel; transport: staged through the host with every stream synchronised around each broadcast, or the product's TorchComm
+    on a gloo group with device tensors (ordered against the posting stream by events only, like RCCL: the schedule's own event edges keep
+    the ranks correct)"""
     import os
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", GPX_PANEL_MESSAGE=message)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29733", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(N), str(d)]
+           "--master-port", "29733", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), str(N), str(d), "full", transport]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded vs single-GPU" in r.stdout
-    assert ("panel message: head + tail" if message == "split" else "panel message: whole") in r.stdout
+    assert ("panel message: head + tail" if message == "split" else "panel message: whole") + ", transport: " + transport in r.stdout
 
 
-def test_sharded_fit_four_ranks_share_one_gpu_c3_size():
-    """The panel-sharded path with FOUR ranks on the one GPU at the C3 size (N = 16384: 16 outer panels, every rank owns four, both
-    staging slots are reused seven times; host-staged transport) against the single-GPU path: estimate_many, call-sharded and
-    row-sharded propagation (Approx and Exact)."""
+@pytest.mark.parametrize("transport", ["host", "gloo-device", "gloo-device-chaos"])
+def test_sharded_fit_four_ranks_share_one_gpu_c3_size(transport):
+    """The panel-sharded path with FOUR ranks on the one GPU at the C3 size (N = 16384: 16 outer panels, every rank owns four, the three
+    staging slots are reused five times; host-staged transport, and TorchComm on gloo with device tensors: 8 MB heads and larger tails as
+    scatter + all-gather) against the single-GPU path: estimate_many, call-sharded and row-sharded propagation (Approx and Exact)."""
     import os
     import subprocess
     import sys
     from conftest import ROOT
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    if transport.endswith("-chaos"):     # random busy-waits on random streams of every rank: late streams must not change the factor
+        env["GPX_SHARD_CHAOS"] = "7"
+        transport = "gloo-device"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
-           "--master-port", "29737", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), "16384", "8", "light"]
+           "--master-port", "29737", os.path.join(ROOT, "tests", "_gpu_shard_worker.py"), "16384", "8", "light", transport]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "sharded vs single-GPU" in r.stdout and "4 ranks, 16 panels" in r.stdout and "panel message: head + tail" in r.stdout
