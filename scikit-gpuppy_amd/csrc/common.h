@@ -181,7 +181,8 @@ int launch_gemm_nt_tri_reduce(const double *A, int64_t lda, const double *B, int
                               double alpha, const GemmReduce &red, hipStream_t s, Profiler *prof);
 int launch_gemm_nt_batched(const double *A, int64_t lda, GemmBatch ba, const double *B, int64_t ldb, GemmBatch bb, double *C, int64_t ldc,
                            GemmBatch bc, int64_t M, int64_t N, int64_t K, double alpha, double beta, int64_t batch, hipStream_t s);
-int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s);
+int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s,
+                             const double *W2 = nullptr);
 int launch_potrf_leaf(double *A, int64_t ld, double *dinv, double *diag_out, int *info_dev, int col_offset,
                       hipStream_t s, Profiler *prof, int exclusive = 0);
 

@@ -202,15 +202,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_trap_signal_kernel(const d
 // the split-K form of a tall-skinny SYRK (contraction >> m) as ONE launch of nchunks x m/128 (m/128 + 1) / 2 tiles -- the caller sums
 // the parts.  (Chunks as launches of their own on several streams share the runtime's few hardware queues and run two or four at a
 // time; one launch lets the caller pick nchunks so that the tiles fill whole rounds of the chip's 512 places.)
-int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s)
+int launch_syrk_lower_splitk(const double *W, int64_t ldw, double *parts, int64_t m, int64_t kchunk, int nchunks, double alpha, hipStream_t s,
+                             const double *W2)
 {
-    if (m % TILE || kchunk % GEMM_BK || kchunk <= 0 || nchunks < 1 || (ldw & 1) || ((uintptr_t)W & 15) || alpha == 0.0) {
+    // W2 (optional, same shape and leading dimension as W): parts = alpha W W2^T, lower tiles only -- for a product the caller knows to be
+    // symmetric (sum_n g_n v_n v_n^T with g split over the two operands)
+    if (!W2) W2 = W;
+    if (m % TILE || kchunk % GEMM_BK || kchunk <= 0 || nchunks < 1 || (ldw & 1) || ((uintptr_t)W & 15) || ((uintptr_t)W2 & 15) || alpha == 0.0) {
         gpx_set_error("launch_syrk_lower_splitk: shape/alignment not supported");
         return GPX_ERR_BAD_ARG;
     }
     const unsigned nt = (unsigned)(m / TILE);
     const GemmBatch bab = {nchunks, 0, (long)kchunk, 0}, bc = {nchunks, 0, (long)(m * m), 0};
-    hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, true>), dim3(nt * (nt + 1) / 2, 1, (unsigned)nchunks), dim3(256), 0, s, W, (long)ldw, W, (long)ldw,
+    hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, true>), dim3(nt * (nt + 1) / 2, 1, (unsigned)nchunks), dim3(256), 0, s, W, (long)ldw, W2, (long)ldw,
                        parts, (long)m, (int)kchunk, alpha, 0.0, 0, 0, (int)nt, bab, bab, bc);
     GPX_HIP(hipGetLastError());
     return 0;

@@ -83,13 +83,14 @@ static int spgp_pick_split(int64_t mp, int64_t np)
 // (gemm.hip: launch_syrk_lower_splitk), summed by one pass.  Round 2 ran eight chunks as eight launches on eight streams: those
 // share four hardware queues, and 8 x 136 tiles are 2.1 rounds of the chip anyway; now the chunk count is chosen so that the tiles
 // fill whole rounds (C5: 64 chunks of 4096 = 17 rounds exactly).
-static int spgp_wtw(gpx_spgp *h, const double *W, double *C, double beta, double alpha = 1.0)
+static int spgp_wtw(gpx_spgp *h, const double *W, double *C, double beta, double alpha = 1.0, const double *W2 = nullptr)
 {
+    // W2 (optional): C = alpha W W2^T + beta C for a product known to be symmetric (lower tiles computed, like W W^T)
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad;
     if (h->split < 2 || !h->split_buf)
-        return launch_gemm_nt(W, np, W, np, C, mp, mp, mp, np, alpha, beta, 1, s, nullptr);
-    GPX_TRY(launch_syrk_lower_splitk(W, np, h->split_buf, mp, np / h->split, h->split, alpha, s));
+        return launch_gemm_nt(W, np, W2 ? W2 : W, np, C, mp, mp, mp, np, alpha, beta, 1, s, nullptr);
+    GPX_TRY(launch_syrk_lower_splitk(W, np, h->split_buf, mp, np / h->split, h->split, alpha, s, W2));
     // the partial buffers' strictly-upper tiles are never written: they were zeroed once at allocation and stay zero
     const long elems = (long)mp * mp;
     hipLaunchKernelGGL(add_partials_kernel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, s, C, (const double *)h->split_buf, elems, h->split, beta);
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void scale_rows_inplace_kernel(double *Z, long
     for (long j = threadIdx.x; j < cols; j += 256) Z[i * ld + j] *= f;
 }
 
-enum { VEC_INV_SQRT = 0, VEC_SNELSON_EP = 1, VEC_MUL = 2, VEC_SUB = 3, VEC_SQUARE = 4, VEC_SQRT_PARTS = 5 };
+enum { VEC_INV_SQRT = 0, VEC_SNELSON_EP = 1, VEC_MUL = 2, VEC_SUB = 3, VEC_SQUARE = 4, VEC_SQRT_PARTS = 5, VEC_DIV = 6 };
 // small elementwise passes over vectors of length npad (n real entries)
 __global__ __launch_bounds__(256) void spgp_vec_kernel(int mode, long n, long npad, double vt, const double *__restrict__ p,
                                                       const double *__restrict__ q, double *__restrict__ o1, double *__restrict__ o2)
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256) void spgp_vec_kernel(int mode, long n, long np
     case VEC_MUL: o1[i] = real ? p[i] * q[i] : 0.0; break;
     case VEC_SUB: o1[i] = real ? p[i] - q[i] : 0.0; break;
     case VEC_SQUARE: o1[i] = real ? p[i] * p[i] : 0.0; break;
+    case VEC_DIV: o1[i] = real ? p[i] / q[i] : 0.0; break;
     case VEC_SQRT_PARTS:    // o1 = sqrt(max(p, 0)), o2 = sqrt(max(-p, 0))
         o1[i] = real ? sqrt(fmax(p[i], 0.0)) : 0.0;
         o2[i] = real ? sqrt(fmax(-p[i], 0.0)) : 0.0;
@@ -587,7 +589,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
     const int d = h->d, dpad = (int)round_up(d, EP_DK), W = 1 + 2 * dpad;
     const int64_t tt = h->mblk * (int64_t)TILE * TILE, mm = mp * mp;
     const int nbE = (int)((np + EP_RB - 1) / EP_RB), nbF = (int)((mp + EP_RB - 1) / EP_RB);
-    double *mats = nullptr, *W2 = nullptr, *vecs = nullptr, *part = nullptr, *small = nullptr;
+    double *mats = nullptr, *W2 = nullptr, *vecs = nullptr, *part = nullptr, *small = nullptr, *Tbuf = nullptr;
     int info = 0;
     std::vector<double> PE((size_t)mp * W), PF((size_t)mp * W), xbw((size_t)mp * d);
     double sg = 0.0;
@@ -603,7 +605,8 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         GPX_TRY(dalloc(&part, (int64_t)std::max(nbE, nbF) * mp * W));
         GPX_TRY(dalloc(&small, 2 * mp * W + 8));
         double *PEd = small, *PFd = PEd + mp * W, *sgd = PFd + mp * W;
-        double *T = h->Wt;                                                                          // [np, mp] once Wt has been consumed
+        GPX_TRY(dalloc(&Tbuf, np * mp));
+        double *T = Tbuf;                                                                           // [np, mp] (Wt = V D^-1/2 stays: the second operand of Qb's product)
 
         GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
         if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
@@ -626,12 +629,13 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
         GPX_TRY(launch_gemm_nt(h->Z, mp, Ainv, mp, T, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));    // T = Zt A^-1
         hipLaunchKernelGGL(spgp_vbar_kernel, dim3((unsigned)((np + 3) / 4)), dim3(256), 0, s, T, (const double *)h->Z, (long)mp, (long)mp, (long)n,
                            (long)np, (const double *)gam, (const double *)h->t, (const double *)betaA, h->vt, gv);   // T = Vbar^T
-        // Qb = V diag(g) V^T - (I - vt A^-1 - betaA betaA^T) / 2 ; g has both signs: two rank-N updates with sqrt(g+), sqrt(g-)
-        GPX_TRY(vec_op(VEC_SQRT_PARTS, n, np, 0.0, gv, nullptr, gpos, gneg, s));
+        // Qb = V diag(g) V^T - (I - vt A^-1 - betaA betaA^T) / 2 ; g has both signs, so it cannot be split as sqrt(g) sqrt(g) over the two
+        // sides of ONE symmetric rank-N update -- but it can be split as (g sqrt(ep)) (1 / sqrt(ep)): the second operand is then Wt = V D^-1/2,
+        // which the fit's own product left in place.  One transposing pass and one lower-only N m^2 product instead of two of each (rounds 2-4:
+        // two updates with sqrt(g+) and sqrt(g-), each over all N rows).
+        GPX_TRY(vec_op(VEC_DIV, n, np, 0.0, gv, isq, gpos, nullptr, s));
         GPX_TRY(spgp_transpose(h, h->Z, gpos, W2));
-        GPX_TRY(spgp_wtw(h, W2, Qb, 0.0, 1.0));
-        GPX_TRY(spgp_transpose(h, h->Z, gneg, W2));
-        GPX_TRY(spgp_wtw(h, W2, Qb, 1.0, -1.0));
+        GPX_TRY(spgp_wtw(h, W2, Qb, 0.0, 1.0, h->Wt));
         GPX_TRY(launch_symmetrize_lower(Qb, mp, mp, s));
         hipLaunchKernelGGL(spgp_qb_fix_kernel, dim3((unsigned)mp), dim3(256), 0, s, Qb, (const double *)Ainv, (const double *)betaA, (long)mp, h->vt);
         GPX_TRY(launch_gemm_nt(T, mp, LinvT, mp, h->Z, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr, 0, GEMM_TRI_B_UPPER));   // Z = Kbar^T = Vbar^T L^-1 (L^-T upper: half the contraction)
@@ -651,7 +655,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
     };
     const int rc = body();
     (void)hipStreamSynchronize(s);
-    dfree(mats); dfree(W2); dfree(vecs); dfree(part); dfree(small);
+    dfree(mats); dfree(W2); dfree(vecs); dfree(part); dfree(small); dfree(Tbuf);
     if (rc) return rc;
     // assemble (coordinates scaled by sqrt(w): (xb - x)^2 w = (xbw - xw)^2)
     std::vector<double> g((size_t)(2 + d + m * d));
