@@ -274,17 +274,19 @@ def spgp_section(n=262144, m=2048, d=8, queries=16384, reps=2):
         t1 = time.perf_counter()
         mu, _var = gp.estimate_many(xs)
         t2 = time.perf_counter()
-        val = gp._dev().nll()
+        g = gp._dev().nll_grad()          # on its own: everything it needs computed in the call
         t3 = time.perf_counter()
-        g = gp._dev().nll_grad()
+        val = gp._dev().nll()             # on its own too (the gradient call overwrote what the two share)
         t4 = time.perf_counter()
+        g = gp._dev().nll_grad()          # right behind the likelihood at the same theta (an L-BFGS step): their common N m^2 part is there
+        t5 = time.perf_counter()
         gp._dev().close()
-        cur = (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+        cur = (t1 - t0, t2 - t1, t4 - t3, t3 - t2, t5 - t4)
         if r:
             best = cur if best is None else tuple(min(a_, b_) for a_, b_ in zip(best, cur))
     flops_fit = 2.0 * n * m * m + 2.0 * m ** 3 / 3.0          # TRSM + lower-only W^T W + two Cholesky
     return {"workload": "C5: SPGP N=%d M=%d d=%d, %d queries" % (n, m, d, queries), "fit_ms": best[0] * 1e3, "estimate_many_ms": best[1] * 1e3,
-            "snelson_nll_ms": best[2] * 1e3, "analytic_gradient_ms": best[3] * 1e3, "train_pts_per_s": n / best[0],
+            "snelson_nll_ms": best[2] * 1e3, "analytic_gradient_ms": best[3] * 1e3, "gradient_after_nll_ms": best[4] * 1e3, "train_pts_per_s": n / best[0],
             "fit_tflops_algorithmic": flops_fit / best[0] / 1e12, "fit_frac_of_peak": flops_fit / best[0] / 1e12 / FP64_MFMA_PEAK_TFLOPS,
             "nll": val, "gradient_finite": bool(np.all(np.isfinite(g))),
             "mean_abs_residual": float(np.abs(mu - np.sin(0.3 * xs.sum(1))).mean())}

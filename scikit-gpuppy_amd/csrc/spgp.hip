@@ -40,6 +40,12 @@ struct gpx_spgp {
     int *info = nullptr;
     int split = 0;                                  // K-chunks of the tall-skinny product W^T W (K = N), 0: one plain launch
     double *split_buf = nullptr;                    // [split][mpad, mpad] partial products
+    // What Snelson's likelihood and its gradient share (spgp_snelson_prepare): with it valid, Z = V^T, Wt = V D^-1/2, va = 1/sqrt(ep),
+    // vb = y/sqrt(ep), vc = log ep, ma = V D^-1 y and scrA = inv(L)^T are as that function left them, and the three buffers below hold the
+    // factor of A = vt I + V D^-1 V^T and gamma.  An L-BFGS step asks for the likelihood and then the gradient at the same theta: the
+    // second call finds the N m^2 part of its work done.  Every other entry point that writes those buffers clears the flag.
+    bool sn_valid = false;
+    double *snA = nullptr, *snDinvA = nullptr, *sndiagA = nullptr, *sngam = nullptr;
 };
 
 // out[i] = beta out[i] + sum_s part[s][i]   (lower tiles matter only; summing everything keeps the kernel trivial)
@@ -196,6 +202,7 @@ extern "C" void gpx_spgp_free(gpx_spgp *h)
     for (void *p : bufs) dfree(p);
     if (h->info) dfree(h->info);
     dfree(h->split_buf);
+    dfree(h->snA); dfree(h->snDinvA); dfree(h->sndiagA); dfree(h->sngam);
     if (h->stream) stream_release(h->stream, 0);
     delete h;
 }
@@ -351,6 +358,7 @@ extern "C" int gpx_spgp_fit(const double *x, const double *t_centered, int64_t n
 extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, double *mean_out, double *var_out)
 {
     GPX_TRY(spgp_require(h));
+    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
     if (ms < 0 || (ms > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_spgp_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
     if (ms == 0) return 0;
     hipStream_t s = h->stream;
@@ -388,51 +396,69 @@ extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, doubl
 }
 
 // Snelson's O(N M^2) negative log likelihood (Covariance.py:981-1019); jitter delta = 1e-6 on K_M as there (:995-998)
-extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
+// The part Snelson's likelihood and its gradient have in common (Covariance.py:981-1019 and the derivation above gpx_spgp_nll_grad):
+// L = chol(K_M + 1e-6 I), Z = V^T = K_NM L^-T, gamma, ep, Wt = V D^-1/2, A = vt I + V D^-1 V^T and its factor, ma = V D^-1 y.
+static int spgp_snelson_prepare(gpx_spgp *h)
 {
-    GPX_TRY(spgp_require(h));
-    if (!nll_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
     hipStream_t s = h->stream;
-    const int64_t np = h->npad, mp = h->mpad, n = h->n, m = h->m;
+    const int64_t np = h->npad, mp = h->mpad, n = h->n;
     const int64_t tt = h->mblk * (int64_t)TILE * TILE;
-    double *L = nullptr, *Dinv = nullptr, *diag = nullptr, *A = nullptr, *DinvA = nullptr, *diagA = nullptr;
+    h->sn_valid = false;
+    if (!h->snA) { GPX_TRY(dalloc(&h->snA, mp * mp)); GPX_TRY(dalloc(&h->snDinvA, tt)); GPX_TRY(dalloc(&h->sndiagA, mp)); GPX_TRY(dalloc(&h->sngam, np)); }
+    double *L = nullptr, *Dinv = nullptr, *diag = nullptr;
     int info = 0;
-    double o[4] = {0, 0, 0, 0};
-    TriSolver ts;
     auto body = [&]() -> int {
         GPX_TRY(dalloc(&L, mp * mp)); GPX_TRY(dalloc(&Dinv, tt)); GPX_TRY(dalloc(&diag, mp));
-        GPX_TRY(dalloc(&A, mp * mp)); GPX_TRY(dalloc(&DinvA, tt)); GPX_TRY(dalloc(&diagA, mp));
         GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
         if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
-        GPX_TRY(spgp_solve_into_z(h, L, Dinv));                                                     // Z = V^T,  V = L^-1 K_MN
-        GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->vb, s, nullptr));   // vb = v + vt - sum V^2
-        GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, h->vb, nullptr, h->va, h->vc, s));             // va = 1/sqrt(ep), vc = log ep
+        GPX_TRY(spgp_solve_into_z(h, L, Dinv, nullptr, h->scrA));                                   // Z = V^T,  V = L^-1 K_MN ; scrA = inv(L)^T
+        GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, h->va, h->sngam, s, nullptr));   // gamma = v + vt - sum V^2
+        GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, h->sngam, nullptr, h->va, h->vc, s));          // va = 1/sqrt(ep), vc = log ep
         GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, h->va, h->vb, nullptr, s));                       // vb = y / sqrt(ep)
         GPX_TRY(spgp_transpose(h, h->Z, h->va, h->Wt));                                             // Wt = V / sqrt(ep)  [M, N]
-        GPX_TRY(launch_set_identity(A, mp, mp, s));
-        GPX_TRY(spgp_wtw(h, h->Wt, A, h->vt));                                                             // A = vt I + V V^T
+        GPX_TRY(launch_set_identity(h->snA, mp, mp, s));
+        GPX_TRY(spgp_wtw(h, h->Wt, h->snA, h->vt));                                                 // A = vt I + V D^-1 V^T
         GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
-        GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));  // Lm
-        GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V y
-        GPX_TRY(ts.prepare(A, mp, h->mblk, DinvA, s, nullptr));
-        GPX_TRY(ts.solve(h->ma, mp, 1, h->mb, nullptr, s, nullptr));                                // bet = Lm^-1 V y
-        std::vector<std::pair<const double *, const double *>> pr;
-        pr.push_back({h->vb, h->vb});
-        GPX_TRY(launch_dot_pairs(pr, np, h->outd, s));                                              // y^T y
-        pr[0] = {h->mb, h->mb};
-        GPX_TRY(launch_dot_pairs(pr, m, h->outd + 1, s));                                           // bet^T bet over the real M
-        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, (const double *)h->vc, (long)np, h->outd + 2);   // sum log ep
-        GPX_TRY(launch_logdet(diagA, m, h->outd + 3, s));                                           // 2 sum log diag(Lm)
+        GPX_TRY(chol_factor(h->snA, mp, h->mblk, h->snDinvA, h->sndiagA, h->info, s, nullptr, nullptr, nullptr));
         GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
-        GPX_HIP(hipMemcpyAsync(o, h->outd, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+        GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, h->vb, 0.0, h->ma, h->mb, s, nullptr));    // ma = V D^-1 y
         GPX_HIP(hipStreamSynchronize(s));
         if (info > 0) { gpx_set_error("vt I + V V^T is not positive definite (leading minor %d)", info); return info; }
         return 0;
     };
     const int rc = body();
     (void)hipStreamSynchronize(s);
+    dfree(L); dfree(Dinv); dfree(diag);
+    if (rc == 0) h->sn_valid = true;
+    return rc;
+}
+
+extern "C" int gpx_spgp_nll(gpx_spgp *h, double *nll_out)
+{
+    GPX_TRY(spgp_require(h));
+    if (!nll_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    hipStream_t s = h->stream;
+    const int64_t np = h->npad, mp = h->mpad, n = h->n, m = h->m;
+    double o[4] = {0, 0, 0, 0};
+    if (!h->sn_valid) GPX_TRY(spgp_snelson_prepare(h));
+    TriSolver ts;
+    auto body = [&]() -> int {
+        GPX_TRY(ts.prepare(h->snA, mp, h->mblk, h->snDinvA, s, nullptr));
+        GPX_TRY(ts.solve(h->ma, mp, 1, h->mb, nullptr, s, nullptr));                                // bet = Lm^-1 V D^-1 y
+        std::vector<std::pair<const double *, const double *>> pr;
+        pr.push_back({h->vb, h->vb});
+        GPX_TRY(launch_dot_pairs(pr, np, h->outd, s));                                              // y^T D^-1 y
+        pr[0] = {h->mb, h->mb};
+        GPX_TRY(launch_dot_pairs(pr, m, h->outd + 1, s));                                           // bet^T bet over the real M
+        hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(256), 0, s, (const double *)h->vc, (long)np, h->outd + 2);   // sum log ep
+        GPX_TRY(launch_logdet(h->sndiagA, m, h->outd + 3, s));                                      // 2 sum log diag(Lm)
+        GPX_HIP(hipMemcpyAsync(o, h->outd, sizeof(double) * 4, hipMemcpyDeviceToHost, s));
+        GPX_HIP(hipStreamSynchronize(s));
+        return 0;
+    };
+    const int rc = body();
+    (void)hipStreamSynchronize(s);
     ts.release();
-    dfree(L); dfree(Dinv); dfree(diag); dfree(A); dfree(DinvA); dfree(diagA);
     if (rc) return rc;
     // fw = sum log diag(Lm) + (N-M)/2 log vt + (y^T y - bet^T bet)/(2 vt) + sum log(ep)/2 + N/2 log 2 pi   (:1017)
     *nll_out = 0.5 * o[3] + 0.5 * (double)(n - m) * log(h->vt) + (o[0] - o[1]) / (2.0 * h->vt) + 0.5 * o[2] + 0.5 * (double)n * log(2.0 * M_PI);
@@ -587,43 +613,31 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad, n = h->n, m = h->m;
     const int d = h->d, dpad = (int)round_up(d, EP_DK), W = 1 + 2 * dpad;
-    const int64_t tt = h->mblk * (int64_t)TILE * TILE, mm = mp * mp;
+    const int64_t mm = mp * mp;
     const int nbE = (int)((np + EP_RB - 1) / EP_RB), nbF = (int)((mp + EP_RB - 1) / EP_RB);
     double *mats = nullptr, *W2 = nullptr, *vecs = nullptr, *part = nullptr, *small = nullptr, *Tbuf = nullptr;
-    int info = 0;
     std::vector<double> PE((size_t)mp * W), PF((size_t)mp * W), xbw((size_t)mp * d);
     double sg = 0.0;
     auto body = [&]() -> int {
-        // M x M: L, A, Ainv, Scr (L^-T), Qb, Y, Qbar, Qk ; blocks' inverses and diagonals
-        GPX_TRY(dalloc(&mats, 8 * mm + 2 * tt + 2 * mp));
-        double *L = mats, *A = L + mm, *Ainv = A + mm, *Scr = Ainv + mm, *Qb = Scr + mm, *Y = Qb + mm, *Qbar = Y + mm, *Qk = Qbar + mm;
-        double *Dinv = Qk + mm, *DinvA = Dinv + tt, *diag = DinvA + tt, *diagA = diag + mp;
+        // M x M: Ainv, Scr (L^-T), Qb, Y, Qbar, Qk
+        GPX_TRY(dalloc(&mats, 6 * mm));
+        double *Ainv = mats, *Scr = Ainv + mm, *Qb = Scr + mm, *Y = Qb + mm, *Qbar = Y + mm, *Qk = Qbar + mm;
         GPX_TRY(dalloc(&W2, mp * np));
-        GPX_TRY(dalloc(&vecs, 7 * np + 3 * mp));
-        double *gam = vecs, *isq = gam + np, *yh = isq + np, *gv = yh + np, *gpos = gv + np, *gneg = gpos + np, *junk = gneg + np;
-        double *ma = junk + np, *betaA = ma + mp, *mj = betaA + mp;
+        GPX_TRY(dalloc(&vecs, 2 * np + 2 * mp));
+        double *gv = vecs, *gpos = gv + np;
+        double *betaA = gpos + np, *mj = betaA + mp;
         GPX_TRY(dalloc(&part, (int64_t)std::max(nbE, nbF) * mp * W));
         GPX_TRY(dalloc(&small, 2 * mp * W + 8));
         double *PEd = small, *PFd = PEd + mp * W, *sgd = PFd + mp * W;
         GPX_TRY(dalloc(&Tbuf, np * mp));
         double *T = Tbuf;                                                                           // [np, mp] (Wt = V D^-1/2 stays: the second operand of Qb's product)
 
-        GPX_TRY(spgp_chol_km(h, 1e-6, L, Dinv, diag, &info));                                       // L = chol(K_M + delta I)
-        if (info > 0) { gpx_set_error("K_M + 1e-6 I is not positive definite (leading minor %d)", info); return info; }
-        double *LinvT = h->scrA;                                                                    // inv(L)^T, explicit and upper triangular: kept for the products below
-        GPX_TRY(spgp_solve_into_z(h, L, Dinv, nullptr, LinvT));                                     // Z = Zt = V^T
-        GPX_TRY(launch_predict_reduce(h->Z, mp, np, mp, h->mzero, h->v + h->vt, junk, gam, s, nullptr));   // gamma = v + vt - |V_n|^2
-        GPX_TRY(vec_op(VEC_SNELSON_EP, n, np, h->vt, gam, nullptr, isq, junk, s));                  // isq = 1 / sqrt(ep), ep = gamma / vt
-        GPX_TRY(vec_op(VEC_MUL, n, np, 0.0, h->t, isq, yh, nullptr, s));
-        GPX_TRY(spgp_transpose(h, h->Z, isq, h->Wt));                                               // Wt = V D^-1/2
-        GPX_TRY(launch_set_identity(A, mp, mp, s));
-        GPX_TRY(spgp_wtw(h, h->Wt, A, h->vt));                                                      // A = vt I + V D^-1 V^T
-        GPX_HIP(hipMemsetAsync(h->info, 0, sizeof(int), s));
-        GPX_TRY(chol_factor(A, mp, h->mblk, DinvA, diagA, h->info, s, nullptr, nullptr, nullptr));
-        GPX_HIP(hipMemcpyAsync(&info, h->info, sizeof(int), hipMemcpyDeviceToHost, s));
-        GPX_TRY(launch_predict_reduce(h->Wt, np, mp, np, yh, 0.0, ma, mj, s, nullptr));             // ma = V D^-1 y
-        GPX_HIP(hipStreamSynchronize(s));
-        if (info > 0) { gpx_set_error("vt I + V V^T is not positive definite (leading minor %d)", info); return info; }
+        // the likelihood's own N m^2 work (factor of K_M, V, gamma, Wt, A and its factor, V D^-1 y): done by a gpx_spgp_nll on this handle
+        // just before (an L-BFGS step), or now
+        if (!h->sn_valid) GPX_TRY(spgp_snelson_prepare(h));
+        h->sn_valid = false;                                                                        // (Z is overwritten below)
+        double *A = h->snA, *DinvA = h->snDinvA, *gam = h->sngam, *isq = h->va, *ma = h->ma;
+        double *LinvT = h->scrA;                                                                    // inv(L)^T, explicit and upper triangular
         GPX_TRY(build_kinv_from_factor(A, mp, h->mblk, DinvA, Scr, Ainv, s, nullptr));              // A^-1
         GPX_TRY(launch_predict_reduce(Ainv, mp, mp, mp, ma, 0.0, betaA, mj, s, nullptr));           // betaA = A^-1 V D^-1 y
         GPX_TRY(launch_gemm_nt(h->Z, mp, Ainv, mp, T, mp, np, mp, mp, 1.0, 0.0, 0, s, nullptr));    // T = Zt A^-1
@@ -686,6 +700,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
 extern "C" int gpx_spgp_dense(gpx_spgp *h, int which, double *out)
 {
     GPX_TRY(spgp_require(h));
+    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
     if (!out || which < 0 || which > 1) { gpx_set_error("gpx_spgp_dense: bad arguments"); return GPX_ERR_BAD_ARG; }
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad, n = h->n;
@@ -719,6 +734,7 @@ extern "C" int gpx_spgp_dense(gpx_spgp *h, int which, double *out)
 extern "C" int gpx_spgp_cross(gpx_spgp *h, const double *xi, int64_t n1, const double *xj, int64_t n2, double *out)
 {
     GPX_TRY(spgp_require(h));
+    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
     if (n1 < 0 || n2 < 0 || ((n1 > 0 && n2 > 0) && (!xi || !xj || !out))) { gpx_set_error("gpx_spgp_cross: bad arguments"); return GPX_ERR_BAD_ARG; }
     if (n1 == 0 || n2 == 0) return 0;
     hipStream_t s = h->stream;

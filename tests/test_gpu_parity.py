@@ -977,9 +977,18 @@ def test_spgp_analytic_gradient_against_oracle(N, d, m):
     th = np.concatenate([np.log([1.7, 0.02]), np.log(rng.uniform(0.02, 0.08, d)), xb.ravel()])
     cov = sk.SPGPCovariance(m)
     gr = cov._d_nll_d_theta(x, t, th)
-    assert cov._negativeloglikelihood(x, t, th) == pytest.approx(orc.spgp_nll(x, t, th, m), rel=1e-9)
+    nll = cov._negativeloglikelihood(x, t, th)
+    assert nll == pytest.approx(orc.spgp_nll(x, t, th, m), rel=1e-9)
     og = orc.spgp_nll_grad(x, t, th, m)
     np.testing.assert_allclose(gr, og, rtol=0, atol=2e-7 * np.abs(og).max())
+    # likelihood and gradient share their N m^2 part (spgp_snelson_prepare): a gradient right behind a likelihood on the same device model
+    # (an L-BFGS step) finds it done, any other call in between clears it -- the same bits either way
+    dev = cov._fit_model(x, t, th)
+    np.testing.assert_array_equal(cov._d_nll_d_theta(x, t, th), gr)            # behind the likelihood above
+    assert dev.nll() == nll and dev.nll() == nll                                 # behind a gradient, then behind a likelihood
+    dev.predict(x[:5])                                                           # overwrites Z and the vector scratch
+    np.testing.assert_array_equal(dev.nll_grad(), gr)
+    np.testing.assert_array_equal(dev.nll_grad(), gr)                            # behind a gradient
 
 
 def test_spgp_full_size_properties():
