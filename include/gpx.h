@@ -195,7 +195,11 @@ void gpx_spgp_free(gpx_spgp *h);
 int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, double *mean /* [ms] */, double *var /* [ms] */);
 int gpx_spgp_nll(gpx_spgp *h, double *nll);
 /* analytic d nll / d (log v, log vt, log w_1..d, pseudo-inputs row-major) in O(N m^2): grad_out [2 + d + m d].  Replaces the
- * reference's dense O(N^2 m)-per-parameter gradient (Covariance.py:906-979, not runnable on Python 3). */
+ * reference's dense O(N^2 m)-per-parameter gradient (Covariance.py:906-979, not runnable on Python 3).
+ * gpx_spgp_nll and gpx_spgp_nll_grad share their common part (the factor of K_M + 1e-6 I, V, gamma, the M x M matrix A and its factor)
+ * on the handle: called one right after the other, in either order -- what an optimiser step does (Covariance.py:314-335: ml_estimate hands
+ * _negativeloglikelihood and _d_nll_d_theta to L-BFGS-B, which evaluates both at every theta) -- the second call reuses it; any other call in between
+ * discards it.  Results do not depend on whether it was reused. */
 int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out);
 int gpx_spgp_dense(gpx_spgp *h, int which, double *out /* [n,n] */);
 int gpx_spgp_cross(gpx_spgp *h, const double *xi, int64_t n1, const double *xj, int64_t n2, double *out /* [n1,n2] */);
