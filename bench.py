@@ -274,14 +274,16 @@ def spgp_section(n=262144, m=2048, d=8, queries=16384, reps=2):
         t1 = time.perf_counter()
         mu, _var = gp.estimate_many(xs)
         t2 = time.perf_counter()
-        g = gp._dev().nll_grad()          # on its own: everything it needs computed in the call
+        val = gp._dev().nll()             # on its own (estimate_many overwrote whatever a likelihood and a gradient share)
         t3 = time.perf_counter()
-        val = gp._dev().nll()             # on its own too (the gradient call overwrote what the two share)
-        t4 = time.perf_counter()
         g = gp._dev().nll_grad()          # right behind the likelihood at the same theta (an L-BFGS step): their common N m^2 part is there
+        t4 = time.perf_counter()
+        gp.estimate_many(xs[:16])         # (discards it again)
         t5 = time.perf_counter()
+        g = gp._dev().nll_grad()          # on its own: everything it needs computed in the call
+        t6 = time.perf_counter()
         gp._dev().close()
-        cur = (t1 - t0, t2 - t1, t4 - t3, t3 - t2, t5 - t4)
+        cur = (t1 - t0, t2 - t1, t3 - t2, t6 - t5, t4 - t3)
         if r:
             best = cur if best is None else tuple(min(a_, b_) for a_, b_ in zip(best, cur))
     flops_fit = 2.0 * n * m * m + 2.0 * m ** 3 / 3.0          # TRSM + lower-only W^T W + two Cholesky

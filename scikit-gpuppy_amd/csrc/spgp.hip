@@ -43,8 +43,9 @@ struct gpx_spgp {
     // What Snelson's likelihood and its gradient share (spgp_snelson_prepare): with it valid, Z = V^T, Wt = V D^-1/2, va = 1/sqrt(ep),
     // vb = y/sqrt(ep), vc = log ep, ma = V D^-1 y and scrA = inv(L)^T are as that function left them, and the three buffers below hold the
     // factor of A = vt I + V D^-1 V^T and gamma.  An L-BFGS step asks for the likelihood and then the gradient at the same theta: the
-    // second call finds the N m^2 part of its work done.  Every other entry point that writes those buffers clears the flag.
-    bool sn_valid = false;
+    // second call finds the N m^2 part of its work done.  Every other entry point that writes those buffers clears the flags.
+    bool sn_valid = false;   // the factor of A, gamma, va / vb / vc, ma, scrA (all the likelihood needs)
+    bool sn_z = false;       // ... and Z, Wt (the gradient needs them too, and overwrites Z)
     double *snA = nullptr, *snDinvA = nullptr, *sndiagA = nullptr, *sngam = nullptr;
 };
 
@@ -358,7 +359,7 @@ extern "C" int gpx_spgp_fit(const double *x, const double *t_centered, int64_t n
 extern "C" int gpx_spgp_predict(gpx_spgp *h, const double *xs, int64_t ms, double *mean_out, double *var_out)
 {
     GPX_TRY(spgp_require(h));
-    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
+    h->sn_valid = h->sn_z = false;   // (writes Z / Wt / the vector scratch)
     if (ms < 0 || (ms > 0 && (!xs || !mean_out || !var_out))) { gpx_set_error("gpx_spgp_predict: bad arguments"); return GPX_ERR_BAD_ARG; }
     if (ms == 0) return 0;
     hipStream_t s = h->stream;
@@ -403,7 +404,7 @@ static int spgp_snelson_prepare(gpx_spgp *h)
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad, n = h->n;
     const int64_t tt = h->mblk * (int64_t)TILE * TILE;
-    h->sn_valid = false;
+    h->sn_valid = h->sn_z = false;
     if (!h->snA) { GPX_TRY(dalloc(&h->snA, mp * mp)); GPX_TRY(dalloc(&h->snDinvA, tt)); GPX_TRY(dalloc(&h->sndiagA, mp)); GPX_TRY(dalloc(&h->sngam, np)); }
     double *L = nullptr, *Dinv = nullptr, *diag = nullptr;
     int info = 0;
@@ -429,7 +430,7 @@ static int spgp_snelson_prepare(gpx_spgp *h)
     const int rc = body();
     (void)hipStreamSynchronize(s);
     dfree(L); dfree(Dinv); dfree(diag);
-    if (rc == 0) h->sn_valid = true;
+    if (rc == 0) h->sn_valid = h->sn_z = true;
     return rc;
 }
 
@@ -634,8 +635,8 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
 
         // the likelihood's own N m^2 work (factor of K_M, V, gamma, Wt, A and its factor, V D^-1 y): done by a gpx_spgp_nll on this handle
         // just before (an L-BFGS step), or now
-        if (!h->sn_valid) GPX_TRY(spgp_snelson_prepare(h));
-        h->sn_valid = false;                                                                        // (Z is overwritten below)
+        if (!(h->sn_valid && h->sn_z)) GPX_TRY(spgp_snelson_prepare(h));
+        h->sn_z = false;                                                                            // (Z is overwritten below; what a likelihood needs stays)
         double *A = h->snA, *DinvA = h->snDinvA, *gam = h->sngam, *isq = h->va, *ma = h->ma;
         double *LinvT = h->scrA;                                                                    // inv(L)^T, explicit and upper triangular
         GPX_TRY(build_kinv_from_factor(A, mp, h->mblk, DinvA, Scr, Ainv, s, nullptr));              // A^-1
@@ -700,7 +701,7 @@ extern "C" int gpx_spgp_nll_grad(gpx_spgp *h, double *grad_out)
 extern "C" int gpx_spgp_dense(gpx_spgp *h, int which, double *out)
 {
     GPX_TRY(spgp_require(h));
-    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
+    h->sn_valid = h->sn_z = false;   // (writes Z / Wt / the vector scratch)
     if (!out || which < 0 || which > 1) { gpx_set_error("gpx_spgp_dense: bad arguments"); return GPX_ERR_BAD_ARG; }
     hipStream_t s = h->stream;
     const int64_t np = h->npad, mp = h->mpad, n = h->n;
@@ -734,7 +735,7 @@ extern "C" int gpx_spgp_dense(gpx_spgp *h, int which, double *out)
 extern "C" int gpx_spgp_cross(gpx_spgp *h, const double *xi, int64_t n1, const double *xj, int64_t n2, double *out)
 {
     GPX_TRY(spgp_require(h));
-    h->sn_valid = false;   // (writes Z / Wt / the vector scratch)
+    h->sn_valid = h->sn_z = false;   // (writes Z / Wt / the vector scratch)
     if (n1 < 0 || n2 < 0 || ((n1 > 0 && n2 > 0) && (!xi || !xj || !out))) { gpx_set_error("gpx_spgp_cross: bad arguments"); return GPX_ERR_BAD_ARG; }
     if (n1 == 0 || n2 == 0) return 0;
     hipStream_t s = h->stream;

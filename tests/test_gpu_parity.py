@@ -985,7 +985,8 @@ def test_spgp_analytic_gradient_against_oracle(N, d, m):
     # (an L-BFGS step) finds it done, any other call in between clears it -- the same bits either way
     dev = cov._fit_model(x, t, th)
     np.testing.assert_array_equal(cov._d_nll_d_theta(x, t, th), gr)            # behind the likelihood above
-    assert dev.nll() == nll and dev.nll() == nll                                 # behind a gradient, then behind a likelihood
+    assert dev.nll() == nll and dev.nll() == nll                                 # behind a gradient (reuses the factor of A), then behind a likelihood
+    np.testing.assert_array_equal(dev.nll_grad(), gr)                            # behind likelihoods that followed a gradient (Z was overwritten: rebuilt)
     dev.predict(x[:5])                                                           # overwrites Z and the vector scratch
     np.testing.assert_array_equal(dev.nll_grad(), gr)
     np.testing.assert_array_equal(dev.nll_grad(), gr)                            # behind a gradient
