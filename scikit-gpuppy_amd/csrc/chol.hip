@@ -898,7 +898,9 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
                 if (panel_final) GPX_TRY((*panel_final)(p, 0, true, nullptr));
                 break;
             }
-            if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles()) {
+            if (s_blk && !reserved && B2 < nblk && (nblk - B2) * (nblk - B2 + 1) / 2 < reserve_below_tiles() && !(sqk_from < 0 && use_sqk(p + 1))) {
+                // (not where the next chain is a square launch already -- small factors, N <= 5120 at the default thresholds: the blockers
+                // would be released again a few lines below, 30 us of memset / placement wait / release on the critical path for nothing)
                 // (the column solves keep their small tiles and share the reserved CUs with the chain: measured better than 224-register
                 // tiles that stay off them, fit 28.9 -> 28.1 ms)
                 GPX_TRY(reserve_now());
