@@ -742,6 +742,7 @@ static int predict_common(gpx_handle *h, const double *xs, const double *kv, con
     // the row sums |z|^2 and z.y ride in the epilogue of each slab's last product (tsolve.hip): per row one partial pair per 64 columns
     const int64_t nslots = h->npad / 64;
     const bool fused = chunk >= 3072;
+    const bool few = m <= 32 && h->tri.ready() && h->tri.P >= 2;
     if ((rc = dalloc(&xq, chunk * std::max(d, 1))) || (rc = dalloc(&xqw, chunk * std::max(d, 1))) || (rc = dalloc(&mv, 2 * chunk)) || (rc = dalloc(&kd, chunk)) ||
         (fused && (rc = dalloc(&part, 2 * chunk * nslots)))) {
         dfree(Zs); if (xq) dfree(xq); if (xqw) dfree(xqw); if (mv) dfree(mv); if (kd) dfree(kd);
@@ -771,6 +772,12 @@ static int predict_common(gpx_handle *h, const double *xs, const double *kv, con
             if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof, &red))) break;
             ProfScope ps(&h->prof, s, GPX_K_REDUCE, 16.0 * (double)mc * (double)nslots);
             if ((rc = launch_predict_finish(red.p2, red.py, nslots, mc, h->v + h->vt, mv, mv + chunk, s, xs ? nullptr : kd))) break;
+        } else if (few) {
+            // a handful of queries (estimate(x_star), plots): the solver for a few right-hand sides -- one forward sweep over the factor's
+            // triangle (HBM-bound, ~0.5 ms at N = 16384) instead of the many-right-hand-side recursion on one 128-row tile (its products
+            // would be 128 x K strips with K up to N/2: 2.5-3 ms)
+            if ((rc = h->tri.solve(h->Z, h->npad, (int)mc, Zs, nullptr, s, &h->prof))) break;
+            if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof, xs ? nullptr : kd))) break;
         } else {
             if ((rc = trsm_right_lt_squares(h->Z, Zs, h->npad, mp, &h->tri, 0, h->tri.P, s, &h->prof))) break;
             if ((rc = launch_predict_reduce(Zs, h->npad, mc, h->npad, h->y, h->v + h->vt, mv, mv + chunk, s, &h->prof, xs ? nullptr : kd))) break;
