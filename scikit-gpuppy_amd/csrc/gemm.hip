@@ -280,7 +280,9 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
     // the dominant kernel = the 128x128-tile launches (>= SMALL_GRID_TILES tiles): profiled at level 1, the rest at level 2.
     // Work = the flops issued: a triangular operand halves the contraction (sum over tile rows / columns of their length).
     const double kfrac = tri ? 0.5 * (1.0 + (double)TILE / (double)K) : 1.0;
-    const bool dominant = tiles >= SMALL_GRID_TILES && !small_tiles;   // (small_tiles: such a launch runs the 64 x 64-tile kernel)
+    const bool tri_b = tri == GEMM_TRI_B_LOWER || tri == GEMM_TRI_B_UPPER;
+    const bool tri_fine = tri_b && tiles >= SMALL_GRID_TILES && tiles < 448.0 && !(C == A || C == B);   // (64 x 64 tiles, below)
+    const bool dominant = tiles >= SMALL_GRID_TILES && !small_tiles && !tri_fine;   // (small_tiles: such a launch runs the 64 x 64-tile kernel)
     ProfScope ps(prof, s, dominant ? GPX_K_GEMM : GPX_K_GEMM_SMALL, tiles * 2.0 * TILE * TILE * (double)K * kfrac, dominant ? 1 : 2);
     const bool in_place = (C == A || C == B);   // in-place TRSM leaves: exactly one column tile per row block
     if (in_place && N != TILE) {
@@ -299,7 +301,14 @@ int launch_gemm_nt(const double *A, int64_t lda, const double *B, int64_t ldb, d
             hipLaunchKernelGGL((gemm_nt_f64_kernel<WM_, WN_, false>), grid, dim3(256), 0, s, A, (long)lda, B, (long)ldb, C, \
                                (long)ldc, (int)K, alpha, beta, 0, ktrim, 0, na_, nb_, nb_);                                  \
     } while (0)
-    if ((tri == GEMM_TRI_B_LOWER || tri == GEMM_TRI_B_UPPER) && tiles >= SMALL_GRID_TILES && (N / TILE) % 2 == 0) {
+    // One triangular operand, B: the tile shape follows the number of places the launch fills (round 5: estimate_many with a few thousand
+    // queries, the K^-1 recursion's leaves, SPGP predictions -- 1024-column leaves whose row count is far below the 16384 the shapes were
+    // tuned on).  Paired 128 x 128 tiles (equal work per workgroup, M/128 * N/256 of them) while they fill most of the chip's 512 places;
+    // below that plain 128 x 128 tiles, longest first (twice the workgroups); below THAT 64 x 64 tiles (eight times): a leaf of 4096 rows
+    // took the same 0.28 ms as one of 16384.
+    const double paired_wgs = (double)(M / TILE) * (double)(N / TILE / 2);
+    if (tri_fine) GPX_LAUNCH(2, 2);
+    else if (tri_b && tiles >= SMALL_GRID_TILES && (N / TILE) % 2 == 0 && paired_wgs >= 448.0) {
         // column tiles of length (bx + 1) * 128 (resp. K - bx * 128): pair bx with its mirror image so that every workgroup does the same work
         const GemmBatch pa_ = {0, 0, 0, tri == GEMM_TRI_B_LOWER ? GEMM_TRI_B_LOWER_PAIRED : GEMM_TRI_B_UPPER_PAIRED};
         hipLaunchKernelGGL((gemm_nt_f64_kernel<4, 4, false>), dim3((unsigned)(N / TILE / 2), (unsigned)(M / TILE)), dim3(256), 0, s, A, (long)lda, B,

@@ -476,7 +476,9 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
     if (!ts || !ts->Pl) { gpx_set_error("trsm_right_lt_squares: solver not prepared"); return GPX_ERR_STATE; }
     if (np == 1) {
         const int64_t k0 = p0 * PB, K = std::min<int64_t>(PB, ts->npad - k0);
-        if (red && (rows / TILE) * (K / TILE) >= 192) {   // the slab's final values leave this product: their row sums ride in its epilogue
+        // the slab's final values leave this product: their row sums ride in its epilogue -- where its paired 128 x 128 tiles fill the chip
+        // (>= 448 of the 512 places); with fewer rows the product takes a finer tile shape (launch_gemm_nt) and the sums a pass of their own
+        if (red && (rows / TILE) * (K / TILE / 2) >= 448) {
             GemmReduce r = *red;
             r.y = red->y + k0;
             r.slot0 = k0 / 64;
