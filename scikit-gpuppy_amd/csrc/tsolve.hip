@@ -494,7 +494,11 @@ int trsm_right_lt_squares(double *Z, double *Zs, int64_t ldz, int64_t rows, cons
     GPX_TRY(trsm_right_lt_squares(Z, Zs, ldz, rows, ts, p0, pm, s, prof, red));
     // Z[:, pm..p1) -= Zs[:, p0..pm) L[pm..p1, p0..pm)^T
     const int64_t c0 = p0 * PB, cm = pm * PB, c1 = std::min<int64_t>(p1 * PB, ts->npad);
-    GPX_TRY(launch_gemm_nt(Zs + c0, ldz, ts->L + cm * ts->ld + c0, ts->ld, Z + cm, ldz, rows, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
+    // (an update that would fill fewer than 448 of the chip's 512 places with 128 x 128 tiles -- a few thousand queries, the short updates at
+    // the bottom of the recursion -- runs on 64 x 64 tiles instead)
+    const double utiles = (double)(rows / TILE) * (double)((c1 - cm) / TILE);
+    GPX_TRY(launch_gemm_nt(Zs + c0, ldz, ts->L + cm * ts->ld + c0, ts->ld, Z + cm, ldz, rows, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof, 0, 0,
+                           utiles >= 192.0 && utiles < 448.0 ? 1 : 0));
     return trsm_right_lt_squares(Z, Zs, ldz, rows, ts, pm, p1, s, prof, red);
 }
 
