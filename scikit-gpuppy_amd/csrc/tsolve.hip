@@ -544,8 +544,11 @@ static int trtri_squares_rec(double *A, double *Zs, int64_t ldz, const TriSolver
     GPX_TRY(trtri_squares_rec(A, Zs, ldz, ts, p0, pm, s, prof));
     const int64_t c0 = p0 * PB, cm = pm * PB, c1 = std::min<int64_t>(p1 * PB, ts->npad);
     const double *Lb = ts->L + cm * ts->ld + c0;
-    if (c0 > 0) GPX_TRY(launch_gemm_nt(Zs + c0, ldz, Lb, ts->ld, A + cm, ldz, c0, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof));
-    GPX_TRY(launch_gemm_nt(Zs + c0 * ldz + c0, ldz, Lb, ts->ld, A + c0 * ldz + cm, ldz, cm - c0, c1 - cm, cm - c0, -1.0, 0.0, 0, s, prof, 1));
+    // (64 x 64 tiles where 128 x 128 ones would fill fewer than 448 of the chip's 512 places, as in estimate_many's recursion)
+    auto fine = [](int64_t r, int64_t c) { const double t = (double)(r / TILE) * (double)(c / TILE); return t >= 192.0 && t < 448.0 ? 1 : 0; };
+    if (c0 > 0) GPX_TRY(launch_gemm_nt(Zs + c0, ldz, Lb, ts->ld, A + cm, ldz, c0, c1 - cm, cm - c0, -1.0, 1.0, 0, s, prof, 0, 0, fine(c0, c1 - cm)));
+    GPX_TRY(launch_gemm_nt(Zs + c0 * ldz + c0, ldz, Lb, ts->ld, A + c0 * ldz + cm, ldz, cm - c0, c1 - cm, cm - c0, -1.0, 0.0, 0, s, prof, 1, 0,
+                           fine(cm - c0, c1 - cm)));
     return trtri_squares_rec(A, Zs, ldz, ts, pm, p1, s, prof);
 }
 
