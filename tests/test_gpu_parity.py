@@ -334,6 +334,12 @@ def test_estimate_many_fused_row_sums_ragged(N, d, M):
     m2, v2 = gp.estimate_many(xs[:1500])
     np.testing.assert_allclose(mean[:1500], m2, rtol=0, atol=1e-11)
     np.testing.assert_allclose(var[:1500], v2, rtol=0, atol=1e-11)
+    # ... and a handful of queries (estimate(x_star), plots): up to 32 go through the few-right-hand-side solver's forward sweep instead of
+    # the many-query recursion (two groups of 16 right-hand sides; 33 is the recursion again) -- the third code path, the same numbers
+    for k in (1, 16, 17, 32, 33):
+        mk, vk = gp.estimate_many(xs[:k])
+        np.testing.assert_allclose(mk, mean[:k], rtol=0, atol=1e-11)
+        np.testing.assert_allclose(vk, var[:k], rtol=0, atol=1e-11)
 
 
 def test_zero_queries():
