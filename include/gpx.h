@@ -162,7 +162,8 @@ int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *
  * Covariance subclass with its own kernel.  C_ux [n] = cov(u, x_i) and cuu = cov(u, u) come from the operator's scalar kernel (host,
  * N calls as in the reference), x [n, d] and w [d] = diag(_get_W_inv()) are handle-free HOST arrays, u [d] / Sigma [d, d] host;
  * K^-1 and beta come from h (any fitted handle, e.g. gpx_fit_matrix) or, with h == NULL, from explicit Kinv [n, n] / beta [n].
- * mean WITHOUT meant; var = cuu - sum_ij (Kinv_ij - beta_i beta_j) C_i C_j corr2_ij - mean^2. */
+ * mean WITHOUT meant; var = cuu - sum_ij (Kinv_ij - beta_i beta_j) C_i C_j corr2_ij - mean^2.  var == NULL: the mean alone
+ * (propagate_mean(u, Sigma, C_ux), UncertaintyPropagation.py:269-290) -- beta . (C corr), no K^-1 is built or read (Kinv may be NULL). */
 int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d, const double *w,
                                const double *C_ux, const double *u, const double *Sigma, double cuu, double *mean, double *var);
 

@@ -1420,10 +1420,17 @@ extern "C" int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigm
 // the reference), x [n, d] and w [d] (the diagonal of _get_W_inv) handle-free, K^-1 and beta from the handle (gpx_fit_matrix or
 // gpx_fit) -- or, with h == NULL, explicit Kinv [n, n] and beta [n] (the reference's Kinv attribute, e.g. of an SPGP model); the
 // N and N^2 sums run in the kernels of the built-in path.  mean WITHOUT meant.
-__global__ __launch_bounds__(256) void mean_lower_kernel(double *A, long ld, long n)
+// lower triangle <- mean of both triangles, padding (rows / columns >= n of the [np, ld] buffer) <- 0, in place: row i's workgroup
+// reads A[j][i], j < i, which no other workgroup writes (those write columns below THEIR row index only)
+__global__ __launch_bounds__(256) void mean_lower_pad_kernel(double *A, long ld, long n, long np)
 {
     const long i = blockIdx.x;
+    if (i >= n) {
+        for (long j = threadIdx.x; j < np; j += 256) A[i * ld + j] = 0.0;
+        return;
+    }
     for (long j = threadIdx.x; j < i; j += 256) A[i * ld + j] = 0.5 * (A[i * ld + j] + A[j * ld + i]);
+    for (long j = n + threadIdx.x; j < np; j += 256) A[i * ld + j] = 0.0;
 }
 
 extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d,
@@ -1432,7 +1439,7 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
 {
     GPX_TRY(gpx_require_device());
     if (h) GPX_HIP(hipSetDevice(h->device));
-    if (!x || !w || !C_ux || !u || !Sigma || n < 1 || d < 1 || d > GPX_MAX_D || (!h && (!Kinv || !beta)) || (h && h->n != n)) {
+    if (!x || !w || !C_ux || !u || !Sigma || n < 1 || d < 1 || d > GPX_MAX_D || (!h && (!beta || (var && !Kinv))) || (h && h->n != n)) {
         gpx_set_error("gpx_propagate_exact_matrix: bad arguments (n=%ld d=%d%s)", (long)n, d, (h && h->n != n) ? ": the handle holds another n" : "");
         return GPX_ERR_BAD_ARG;
     }
@@ -1441,7 +1448,8 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
     const int64_t np = round_up(n, TILE);
     hipStream_t s = h ? h->stream : nullptr;
     const double *kbase = nullptr, *bdev = nullptr;
-    if (h) { GPX_TRY(ensure_kinv(h)); kbase = h->Kinv; bdev = h->alpha; }
+    const bool want_var = var != nullptr;   // the mean is beta . l alone: no K^-1 (46 ms to build at C3), no N^2 pass
+    if (h) { if (want_var) { GPX_TRY(ensure_kinv(h)); kbase = h->Kinv; } bdev = h->alpha; }
     // constants (UncertaintyPropagation.py:247-257, :292-303) exactly as exact_common builds them
     std::vector<double> A((size_t)d * d), Ai((size_t)d * d), Ls((size_t)d * d), dd(d);
     double nc1 = 1.0, nc2 = 1.0;
@@ -1462,7 +1470,7 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
             const double lji = (i == j ? 2.0 * w[i] : 0.0) - Ai[(size_t)j * d + i];
             Ls[(size_t)i * d + j] = 0.5 * (lij + lji);
         }
-    double *buf = nullptr, *Kd = nullptr, *Kp = nullptr;
+    double *buf = nullptr, *Kp = nullptr;
     const int64_t need = (2 * (int64_t)d + 6) * np + n * (int64_t)d + (int64_t)d * d + 2 * d + 8;
     GPX_TRY(dalloc(&buf, need));
     double *aT = buf, *bT = aT + (int64_t)d * np, *e = bT + (int64_t)d * np, *F = e + np, *lm = F + np, *partial = lm + np;
@@ -1477,27 +1485,29 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
         if ((er = hipMemcpyAsync(xd, x, sizeof(double) * n * d, hipMemcpyDefault, s)) != hipSuccess) break;
         if ((er = hipMemcpyAsync(Cd, C_ux, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
         if (!h) {
-            // explicit K^-1 / beta: zero-padded beta, K^-1 padded to the tile grid (the padding never enters: F = 0 there)
-            if ((rc = dalloc(&Kd, n * n)) || (rc = dalloc(&Kp, np * np))) break;
-            if ((er = hipMemcpyAsync(Kd, Kinv, sizeof(double) * n * n, hipMemcpyDefault, s)) != hipSuccess) break;
-            hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)np), dim3(256), 0, s, (const double *)Kd, (long)n, Kp, (long)np, 0.0);
-            // the pair kernel visits j <= i only (weight 2) where the reference sums both triangles: the lower triangle of a supplied
-            // K^-1 becomes the mean of both (a Woodbury-built inverse is symmetric to rounding only)
-            hipLaunchKernelGGL(mean_lower_kernel, dim3((unsigned)n), dim3(256), 0, s, Kp, (long)np, (long)n);
+            // explicit K^-1 / beta: zero-padded beta; K^-1 goes row by row straight into ONE buffer padded to the tile grid (the
+            // padding never enters: F = 0 there).  The pair kernel visits j <= i only (weight 2) where the reference sums both
+            // triangles: the lower triangle of a supplied K^-1 becomes the mean of both (a Woodbury-built inverse is symmetric to
+            // rounding only).  Mean only: no K^-1 at all.
+            if (want_var) {
+                if ((rc = dalloc(&Kp, np * np))) break;
+                if ((er = hipMemcpy2DAsync(Kp, sizeof(double) * np, Kinv, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDefault, s)) != hipSuccess) break;
+                hipLaunchKernelGGL(mean_lower_pad_kernel, dim3((unsigned)np), dim3(256), 0, s, Kp, (long)np, (long)n, (long)np);
+                kbase = Kp;
+            }
             if ((er = hipMemsetAsync(bpad, 0, sizeof(double) * np, s)) != hipSuccess) break;
             if ((er = hipMemcpyAsync(bpad, beta, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
-            kbase = Kp; bdev = bpad;
+            bdev = bpad;
         }
         if ((rc = launch_exact_build_generic(xd, n, np, d, ud, Lsd, ddd, Cd, nc1, aT, bT, e, F, lm, s))) break;
         std::vector<std::pair<const double *, const double *>> pr;
         pr.push_back({bdev, lm});
         if ((rc = launch_dot_pairs(pr, np, outd, s))) break;
-        if ((rc = launch_exact_sum(kbase, np, np, d, bdev, aT, bT, e, F, partial, outd + 1, s, h ? &h->prof : nullptr))) break;
-        if ((er = hipMemcpyAsync(o, outd, sizeof(double) * 2, hipMemcpyDeviceToHost, s)) != hipSuccess) break;
+        if (want_var && (rc = launch_exact_sum(kbase, np, np, d, bdev, aT, bT, e, F, partial, outd + 1, s, h ? &h->prof : nullptr))) break;
+        if ((er = hipMemcpyAsync(o, outd, sizeof(double) * (want_var ? 2 : 1), hipMemcpyDeviceToHost, s)) != hipSuccess) break;
     } while (0);
     const hipError_t es = hipStreamSynchronize(s);
     dfree(buf);
-    if (Kd) dfree(Kd);
     if (Kp) dfree(Kp);
     if (rc) return rc;
     if (er != hipSuccess || es != hipSuccess) { gpx_set_error("gpx_propagate_exact_matrix: %s", hipGetErrorString(er != hipSuccess ? er : es)); return GPX_ERR_HIP; }

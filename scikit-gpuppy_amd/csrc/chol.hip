@@ -371,10 +371,12 @@ static void retire_buffers(const std::vector<void *> &bufs, hipStream_t behind) 
 // status words of a square launch (dflow.hip: [0] potrf status, [1] stall) folded into the caller's ONE status word: a non-positive
 // pivot as it is, an expired in-kernel wait as GPX_INFO_STALLED (the multi-GPU host raises on it: that factor is invalid, and it is not
 // a property of K -- never answered with jitter)
+// Launched on up to three unjoined streams (s, sh, sf): the merge is monotonic -- STALLED is the largest value, and atomicMax / a
+// compare-and-swap from 0 cannot put a pivot index over a STALLED another stream's merge has written in between.
 __global__ void merge_info_kernel(const int *two, int *one)
 {
-    if (two[1]) *one = GPX_INFO_STALLED;
-    else if (two[0] && *one == 0) *one = two[0];
+    if (two[1]) atomicMax(one, (int)GPX_INFO_STALLED);
+    else if (two[0]) atomicCAS(one, 0, two[0]);
 }
 
 // The panel step of the multi-GPU host's panel owner (skgpuppy_amd/distributed.py -> gpx_dev_chol_panel / gpx_dev_chol_panel_next /
@@ -723,7 +725,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // rank-128 update) = 24 dependent launches -- is ONE small launch of the dataflow kernel on the panel's square (leaf + side workers,
     // dflow.hip), and the column solves of the rows below wait for its step counter instead of for events.
     // Used where the chain is the critical path and the chip has empty CUs for it: for the panels whose trailing update has fewer than
-    // GPX_SQK_TILES tiles left (default 1000: the last six panels at N = 16384), and -- GPX_SQK_FIRST, default on -- for the first panel
+    // GPX_SQK_TILES tiles left (default 1000: the last six panels at N = 16384), and for the first panel
     // (nothing but the Gram kernel's remainder runs beside it).  GPX_SQK_FROM = p forces it from panel p on (0: everywhere; -1: never).
     static const int64_t sqk_from = [] { const char *e = getenv("GPX_SQK_FROM"); return e ? atol(e) : (int64_t)-2; }();
     static const long sqk_tiles = [] { const char *e = getenv("GPX_SQK_TILES"); return e ? atol(e) : 1000L; }();
@@ -732,7 +734,7 @@ int chol_factor(double *L, int64_t ld, int64_t nblk, double *Dinv, double *diagL
     // State words: 1024 ints per panel (chol_dataflow_state_ints(8) = 656), zeroed on the MAIN stream in front of the factorisation's first
     // event -- the column solves on s_top poll them, and a recycled buffer holds the previous fit's finished counters; the task tables of
     // a full square and of a shorter last one are uploaded once, behind the states.
-    // GPX_SQK_NEXT (default 1): the square launch also solves the NEXT diagonal square's rows for its columns (COL tasks of GPX_SQK_EXTRA
+    // The square launch also solves the NEXT diagonal square's rows for its columns (COL tasks of sqk_extra
     // more workgroups, in step with the chain), so that the update of the next square -- what the next chain waits for -- follows the
     // launch at once instead of waiting for the column solves of ALL rows below on the third stream; those keep the rows further down,
     // which only the trailing update needs.  The rows reach the launch through another stream's update: gate word per panel, set behind it.

@@ -405,7 +405,12 @@ static int spgp_snelson_prepare(gpx_spgp *h)
     const int64_t np = h->npad, mp = h->mpad, n = h->n;
     const int64_t tt = h->mblk * (int64_t)TILE * TILE;
     h->sn_valid = h->sn_z = false;
-    if (!h->snA) { GPX_TRY(dalloc(&h->snA, mp * mp)); GPX_TRY(dalloc(&h->snDinvA, tt)); GPX_TRY(dalloc(&h->sndiagA, mp)); GPX_TRY(dalloc(&h->sngam, np)); }
+    // four persistent buffers, each checked on its own: a failed later allocation must not leave a non-null snA behind that makes the
+    // next call skip the allocation and launch on null pointers
+    if (!h->snA) GPX_TRY(dalloc(&h->snA, mp * mp));
+    if (!h->snDinvA) GPX_TRY(dalloc(&h->snDinvA, tt));
+    if (!h->sndiagA) GPX_TRY(dalloc(&h->sndiagA, mp));
+    if (!h->sngam) GPX_TRY(dalloc(&h->sngam, np));
     double *L = nullptr, *Dinv = nullptr, *diag = nullptr;
     int info = 0;
     auto body = [&]() -> int {

@@ -267,21 +267,26 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
         w = _gpx.f64(np.diag(self.Winv))
         cuu = float(gp._covariance(u, u)) if want_var else 0.0
         mean, var = ctypes.c_double(), ctypes.c_double()
-        if gp._route() == "generic":
+        pvar = ctypes.byref(var) if want_var else None      # mean only: the library neither builds nor reads K^-1
+        if gp._route() in ("generic", "gaussian"):
+            # (any fitted handle: a gpx_fit_matrix one, or -- a caller-supplied C_ux on the built-in route -- the gpx_fit one)
             st = _gpx.lib.gpx_propagate_exact_matrix(gp._dev().handle, None, None, _gpx.ptr(x), gp.n, gp.d, _gpx.ptr(w), _gpx.ptr(C),
-                                                     _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), ctypes.byref(var))
+                                                     _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), pvar)
         else:
             # (SPGP: the model's dense K^-1 -- what the reference's class reads through _inv_cov_matrix -- and beta = Kinv t)
-            Kinv, beta = _gpx.f64(gp._inv_cov_matrix()), _gpx.f64(gp._get_beta())
-            st = _gpx.lib.gpx_propagate_exact_matrix(None, _gpx.ptr(Kinv), _gpx.ptr(beta), _gpx.ptr(x), gp.n, gp.d, _gpx.ptr(w), _gpx.ptr(C),
-                                                     _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), ctypes.byref(var))
+            Kinv = _gpx.f64(gp._inv_cov_matrix()) if want_var else None
+            beta = _gpx.f64(gp._get_beta())
+            st = _gpx.lib.gpx_propagate_exact_matrix(None, _gpx.ptr(Kinv) if want_var else None, _gpx.ptr(beta), _gpx.ptr(x), gp.n, gp.d,
+                                                     _gpx.ptr(w), _gpx.ptr(C), _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), pvar)
         _gpx.check(st, "gpx_propagate_exact_matrix")
         return mean.value, var.value
 
     def propagate_mean(self, u, Sigma_x, C_ux=None):
-        # (UncertaintyPropagation.py:269-290); with the built-in kernel C_ux is rebuilt on the device (accepted for signature parity)
+        # (UncertaintyPropagation.py:269-290).  A caller-supplied C_ux is USED, as in the reference's class (sum_i beta_i C_ux_i corr_i):
+        # on the built-in route too it goes through gpx_propagate_exact_matrix on the fitted handle; without one the device builds
+        # C(u, x_i) itself (gpx_exact_mean).
         self._set_constants(u, np.asarray(Sigma_x, dtype=float))
-        if self.gp._route() != "gaussian":
+        if self.gp._route() != "gaussian" or C_ux is not None:
             return np.float64(self._generic_moments(u, Sigma_x, C_ux, False)[0])
         uu, S = _u_sigma(self.gp, u, Sigma_x)
         out = ctypes.c_double()

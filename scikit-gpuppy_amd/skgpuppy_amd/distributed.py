@@ -38,6 +38,7 @@ import numpy as np
 TILE = 128
 PANEL_BLOCKS = 8     # outer panel = 8 x 128 = 1024 columns (same as csrc/chol.hip CHOL_NBP)
 JITTER = 1e-5        # skgpuppy/Covariance.py:182
+INFO_STALLED = 0x3fffffff   # GPX_INFO_STALLED (include/gpx.h): an in-kernel hand-off of a panel step timed out -- not a property of K
 
 
 class PanelLayout(object):
@@ -579,11 +580,10 @@ class GpxOps(object):
         if self._timed:
             self.timing = {k: float(sum(a.elapsed_time(b) for a, b in v)) for k, v in self._pairs.items()}
             self.timing["panels_owned"] = len(self._pairs["chol_panel_ms"])
-        info = int(self.info.item())
-        if info == 0x3fffffff:       # GPX_INFO_STALLED (include/gpx.h): an in-kernel hand-off of a panel step timed out -- not a property of K
-            raise RuntimeError("rank %d: a hand-off inside a panel step of the sharded factorisation timed out (GPX_WAIT_LIMIT_MS); "
-                               "the factor is invalid" % self.rank)
-        return info
+        # The raw status word: 0, a 1-based failing column, or GPX_INFO_STALLED.  Only the owner of a stalled panel sees that value, so
+        # nothing is raised HERE -- panel_cholesky's max_int carries it to every rank (it is the largest value) and the caller raises
+        # on all of them after the collective (a rank that threw alone would leave the others blocked in the all-reduce).
+        return int(self.info.item())
 
 
 def combine_approx_partials(o, Sigma, v, vt):
@@ -649,6 +649,11 @@ class ShardedGaussianProcess(object):
         self._t_dev = torch.as_tensor(_gpx.f64(self.t)).to(self.device)
         self.layout = PanelLayout(self.n, self.world, split=split)
         self._comm = comm if comm is not None else TorchComm(group)
+        # GPX_PANEL_MESSAGE is read per rank: ranks that disagreed would post mismatched collectives (head + tail against one part)
+        # and hang.  Agree once, collectively, and fail on every rank if they differ.
+        flag = int(self.layout.split)
+        if self._comm.max_int(flag) != flag or -self._comm.max_int(-flag) != flag:
+            raise RuntimeError("ranks disagree on the panel message form (GPX_PANEL_MESSAGE / split=): set it identically on every rank")
         self._ops = None
         self._h = ctypes.c_void_p()
         self.jitter = 0.0
@@ -668,6 +673,11 @@ class ShardedGaussianProcess(object):
                 if info == 0:
                     break
                 del ops
+                if info == INFO_STALLED:
+                    # agreed by the all-reduce inside panel_cholesky: EVERY rank raises, before the jitter retry (a timed-out
+                    # hand-off is not a property of K and is never answered with +1e-5 I, include/gpx.h)
+                    raise RuntimeError("a hand-off inside a panel step of the sharded factorisation timed out on some rank "
+                                       "(GPX_WAIT_LIMIT_MS); the factor is invalid")
             if info > 0:
                 raise np.linalg.LinAlgError("covariance matrix not positive definite (leading minor %d), also with +1e-5 jitter" % info)
             self._ops = ops

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "scikit-gpuppy_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
-from skgpuppy_amd.distributed import TILE, PanelLayout, TorchComm, panel_cholesky  # noqa: E402
+from skgpuppy_amd.distributed import INFO_STALLED, TILE, PanelLayout, TorchComm, panel_cholesky  # noqa: E402
 from oracle import oracle as orc  # noqa: E402
 
 
@@ -105,8 +105,10 @@ class CpuOps(object):
             self.L[c1 + hr:, c0:c1] = rest
             self.L[c0:c1, c0:c1] = buf[(below - hr) * w:(below - hr) * w + w * w].view(w, w)
 
+    stall_on_rank = None      # test hook: this rank's status word reports a timed-out hand-off (GPX_INFO_STALLED)
+
     def finish(self):
-        return 0
+        return INFO_STALLED if self.rank == self.stall_on_rank else 0
 
 
 def main():
@@ -117,10 +119,20 @@ def main():
     x = rng.uniform(0, 5, (n, d))
     theta = np.log(np.array([1.5, 0.05, 0.3, 0.2, 0.4]))
     mode = sys.argv[3] if len(sys.argv) > 3 else "bcast"
+    stall = mode.endswith("-stall")
     layout = PanelLayout(n, world, panel_blocks=pb, split=not mode.endswith("-whole"))
     ops = CpuOps(x, theta, layout, rank)
+    if stall:
+        ops.stall_on_rank = world - 1
     # split_bytes=1: every message whose length the world size divides travels as scatter + all-gather
     info = panel_cholesky(ops, layout, rank, TorchComm(split_bytes=1 if mode.startswith("split") else 1 << 40))
+    if stall:
+        # ONE rank's status word says "stalled": no rank throws before the collective, every rank learns it from the all-reduce
+        # (a rank that raised alone would leave the others blocked in it) -- the caller then raises on all of them
+        assert info == INFO_STALLED, info
+        print("rank %d: stalled status agreed" % rank)
+        dist.destroy_process_group()
+        sys.exit(0)
     assert info == 0
     with np.errstate(divide="ignore"):
         K = orc.gram(x, theta)

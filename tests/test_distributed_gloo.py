@@ -22,6 +22,23 @@ def test_panel_cholesky_gloo(n, pb, world, mode):
     assert "max |L - Lref|" in r.stdout
 
 
+def test_stalled_status_reaches_every_rank_without_a_hang():
+    """only the owner of a stalled panel sees GPX_INFO_STALLED in its status word.  GpxOps.finish() must not raise on that
+    rank alone (the others would block in the all-reduce until the backend's timeout): the raw word goes through panel_cholesky's
+    max_int and every rank gets it; ShardedGaussianProcess.refit raises on all of them, before the jitter retry."""
+    import inspect
+    from skgpuppy_amd import distributed as D
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", "29711", os.path.join(ROOT, "tests", "_gloo_worker.py"), "390", "1", "bcast-stall"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("stalled status agreed") == 3
+    assert "raise RuntimeError" not in inspect.getsource(D.GpxOps.finish)                      # the product's finish() hands the word on
+    src = inspect.getsource(D.ShardedGaussianProcess.refit)
+    assert src.index("INFO_STALLED") < src.index("if info > 0")                   # raised collectively, not answered with jitter
+
+
 def test_layout_ownership():
     from skgpuppy_amd.distributed import PanelLayout
     lay = PanelLayout(65536, 8)

@@ -253,6 +253,10 @@ def test_propagation_golden(case):
                 assert me == pytest.approx(g[key][0], abs=1e-9 * k)
                 assert ve == pytest.approx(g[key][1], abs=1e-8 * v * k)
                 assert upe.propagate_mean(u, S) == pytest.approx(float(g["exact_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
+                # a caller-supplied C_ux is USED on the built-in route too (reference: UncertaintyPropagation.py:269-290)
+                mc = upe.propagate_mean(u, S, g["C_alt_u%d" % iu])
+                assert mc == pytest.approx(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
+                assert abs(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]) - float(g["exact_mean_only_u%d_S%d" % (iu, iS)])) > 1e-6 * k   # (the fixture tells the two apart)
 
 
 def test_kat1_quirk_active():

@@ -83,6 +83,9 @@ def test_propagation(case):
                 assert ve == pytest.approx(g[key][1], abs=tol)
                 mo = orc.exact_mean(gp, u, S)
                 assert mo == pytest.approx(float(g["exact_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-10)
+                # propagate_mean(u, Sigma, C_ux) with a caller-supplied C_ux (UncertaintyPropagation.py:269-290)
+                mc = orc.exact_mean(gp, u, S, C=g["C_alt_u%d" % iu])
+                assert mc == pytest.approx(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]), abs=1e-10)
 
 
 def test_kat1_known_answers():

@@ -152,6 +152,11 @@ def gp_case(GC, GP, UP, x, t, theta, xs, us, Sigmas, v_out=0.02, keep_kinv=True,
                 me, ve = upe.propagate_GA(u, S)
                 o["exact_u%d_S%d" % (iu, iS)] = np.array([me, ve])
                 o["exact_mean_only_u%d_S%d" % (iu, iS)] = np.float64(upe.propagate_mean(u, S))
+                # propagate_mean with a CALLER-SUPPLIED C_ux on the built-in operator (UncertaintyPropagation.py:269-290: it is used
+                # instead of gp._covariance(u, x_i)); a vector that is not the GP's own
+                C_alt = 0.5 * np.asarray(upa.C_ux, dtype=float).reshape(-1) * (1.0 + 0.1 * np.cos(np.arange(x.shape[0])))
+                o["C_alt_u%d" % iu] = C_alt
+                o["exact_mean_C_alt_u%d_S%d" % (iu, iS)] = np.float64(upe.propagate_mean(u, S, C_alt))
     o["v_out"] = np.float64(v_out)
     # "next" row f1: likelihood and gradient at this theta (and at a perturbed one), centred targets as the GP passes them
     for tag, th in (("", np.array(theta, dtype=float)), ("_p", np.array(theta, dtype=float) * 0.9 + 0.05)):
