@@ -255,7 +255,9 @@ def test_propagation_golden(case):
                 assert upe.propagate_mean(u, S) == pytest.approx(float(g["exact_mean_only_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
                 # a caller-supplied C_ux is USED on the built-in route too (reference: UncertaintyPropagation.py:269-290)
                 mc = upe.propagate_mean(u, S, g["C_alt_u%d" % iu])
-                assert mc == pytest.approx(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]), abs=1e-9 * k)
+                # (C_alt is not a covariance vector: sum_i beta_i C_alt_i does not cancel like beta . C, so the value is O(|beta|_1) --
+                # 14 on METIS -- and carries the LU-vs-Cholesky difference of beta in RELATIVE terms: SURVEY 8a, 1e-9 .. 2e-7)
+                assert mc == pytest.approx(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]), abs=1e-9 * k, rel=1e-8 * k)
                 assert abs(float(g["exact_mean_C_alt_u%d_S%d" % (iu, iS)]) - float(g["exact_mean_only_u%d_S%d" % (iu, iS)])) > 1e-6 * k   # (the fixture tells the two apart)
 
 
