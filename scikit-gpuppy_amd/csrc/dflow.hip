@@ -211,13 +211,13 @@ __device__ __noinline__ void slab_update(const DflowParams &p, int i, int j, int
     const double *A = tile_ptr(p, i, ka) + (long)(32 * s) * p.ld;
     const double *B = tile_ptr(p, j, ka);
     double *C = tile_ptr(p, i, j) + (long)(32 * s) * p.ld;
-    gemm_tile<1, 4, 3>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (kb - ka) * TILE, -1.0, 1.0, smem, true);
+    gemm_tile<1, 4>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (kb - ka) * TILE, -1.0, 1.0, smem, true);
 }
 
 // slab (32 rows at C) <- slab inv(L_kk)^T in place
 __device__ __noinline__ void slab_solve(const DflowParams &p, double *C, int k, double *smem)
 {
-    gemm_tile<1, 4, 3>(C, p.ld, p.Dinv + (long)(p.c0 + k) * TILE * TILE, TILE, C, p.ld, 0, 0, 0, TILE, 1.0, 0.0, smem, true);
+    gemm_tile<1, 4>(C, p.ld, p.Dinv + (long)(p.c0 + k) * TILE * TILE, TILE, C, p.ld, 0, 0, 0, TILE, 1.0, 0.0, smem, true);
 }
 
 // COL(i, k, s): L[i][k][slab] = (A[i][k] - sum_{m in panel, m < k} L[i][m] L[k][m]^T)[slab] inv(L_kk)^T.  The sum over all but the last
@@ -242,11 +242,11 @@ __device__ __noinline__ bool run_col(const DflowParams &p, int i, int k, int s, 
     const unsigned long long t1 = STAMP(p);
     if (k > ka) {
         v4d acc[1][4];
-        gemm_tile_x<1, 4, 3>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (k - 1 - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_INIT);
+        gemm_tile_x<1, 4>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (k - 1 - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_INIT);
         Deps d;
         d.add(st_prog(p, i, s), k);
         if (wait_deps(p, d, true, s_res) < 0) return false;
-        gemm_tile_x<1, 4, 3>(A, p.ld, B, p.ld, C, p.ld, 0, 0, (long)(k - 1 - ka) * TILE, (k - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_STORE);
+        gemm_tile_x<1, 4>(A, p.ld, B, p.ld, C, p.ld, 0, 0, (long)(k - 1 - ka) * TILE, (k - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_STORE);
     }
     {
         // every wave drains its write-through stores of the slab; the wait below ends in one agent-scope acquire + workgroup barrier, so
@@ -288,14 +288,14 @@ __device__ __noinline__ bool run_diag(const DflowParams &p, int k, int s, double
         if (wait_deps(p, d, true, s_res) < 0) return false;
     }
     const unsigned long long t1 = STAMP(p);
-    gemm_tile_x<1, 4, 3>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (k - 1 - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_INIT);
+    gemm_tile_x<1, 4>(A, p.ld, B, p.ld, C, p.ld, 0, 0, 0, (k - 1 - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_INIT);
     {
         Deps d;
         for (int u = 0; u < 4; ++u) d.add(st_prog(p, k, u), k);
         if (wait_deps(p, d, true, s_res) < 0) return false;
     }
     const unsigned long long t2 = STAMP(p);
-    gemm_tile_x<1, 4, 3>(A, p.ld, B, p.ld, C, p.ld, 0, 0, (long)(k - 1 - ka) * TILE, (k - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_STORE);
+    gemm_tile_x<1, 4>(A, p.ld, B, p.ld, C, p.ld, 0, 0, (long)(k - 1 - ka) * TILE, (k - ka) * TILE, -1.0, 1.0, smem, true, acc, GT_STORE);
     publish_add(p.st + ST_DIAGCNT + k, 1);
     trace_event(p, 2, k, k, s, t0, t1, t2, STAMP(p));
     return true;

@@ -17,7 +17,6 @@
 #include "common.h"
 
 #include "gemm_tile.h"
-#include "gemm_tile_old.h"
 
 // Row reduction fused into a product's epilogue (estimate_many: the last product that touches a slab of Zs = kv L^-T is the one with the
 // slab's inverted square -- GaussianProcess.py:77-78 needs only  sum_c z_mc^2  and  sum_c z_mc y_c  of every row): each wave adds up its
@@ -125,11 +124,9 @@ __device__ __forceinline__ void gemm_nt_f64_body(const double *A, long lda, cons
         if (RED) {
             v4d acc[WM][WN];
             gemm_tile_x<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem, false, acc, GT_INIT | GT_STORE);
-            tile_row_reduce<WM, WN>(acc, 1.0, red, bx, by);   // (GT_STORE left the scaled result in the accumulators)
-        } else if (WM == 4 && WN == 4)
+            tile_row_reduce<WM, WN>(acc, alpha, red, bx, by);
+        } else
             gemm_tile<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);
-        else
-            gemm_tile_old<WM, WN>(A, lda, B, ldb, C, ldc, bx, by, kstart, kend, alpha, beta, smem);   // EXPERIMENT: small tiles keep the round-5 body
     }
 }
 
@@ -138,10 +135,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f64_kernel(const double *A, lo
                                                             double *C, long ldc, int K, double alpha, double beta, int tri_off, int ktrim, int tri_rows,
                                                             GemmBatch ba, GemmBatch bb, GemmBatch bc)
 {
-    // The 128 x 128-tile kernel must NOT fit into the 216 registers the CU blockers leave per SIMD (chol.hip): a bulk workgroup that
-    // settles on a reserved CU takes the LDS the chain's leaf needs there.  The compiler needs fewer since round 6 (the C tile is addressed
-    // from SGPRs): pinned like the trapezoid kernel.  tests/test_kernel_resources.py guards the budget.
-    if (WM == 4 && WN == 4) asm volatile("v_mov_b32 v223, 0" ::: "v223");
     gemm_nt_f64_body<WM, WN, LOWER, false>(A, lda, B, ldb, C, ldc, K, alpha, beta, tri_off, ktrim, tri_rows, ba, bb, bc, GemmReduce{});
 }
 
