@@ -1410,7 +1410,7 @@ def test_two_threads_large_fits_do_not_stall():
     """SURVEY.md 8b threading row at sizes that take the whole look-ahead machinery (CU blockers, square launches that hold whole CUs,
     kernels that wait for kernels of other streams): two host threads, each three fits at N = 12288 and one at 16384 on handles of
     its own, at the same time.  No in-kernel hand-off may stall (GPX_DEBUG would say so: a stall costs 5 s and a refit), alpha must
-    be the serial run's (bit for bit when no fit took a fall-back schedule), and running side by side must not cost more than 2.5x the
+    be the serial run's (bit for bit when no fit took a fall-back schedule), and running side by side must not cost more than 1.55x the
     serial sum.  The reference's objects are plain Python and freely concurrent (GaussianProcess.py:19-41)."""
     import os
     import subprocess
@@ -1425,7 +1425,9 @@ def test_two_threads_large_fits_do_not_stall():
     val = {l.split()[0]: float(l.split()[1]) for l in r.stdout.splitlines() if l.split() and l.split()[0].endswith(("SECONDS", "DIFF"))}
     print("two threads, large fits:", val)
     assert val["WORST_REL_DIFF"] <= 1e-10, val       # (a thread whose stream pair was probed under load may take the serialised schedule: same factor to rounding)
-    assert val["CONCURRENT_SECONDS"] <= 2.5 * val["SERIAL_SECONDS"] + 0.05, val
+    # measured (profiles/r06_concurrent_fits_ratio.txt): 1.08-1.28 x the serial sum since only one look-ahead fit runs per device at a
+    # time; the bound is the worst measured ratio + 20 % (it was 2.5 x, and the schedule before that fix ran at 3.3 x)
+    assert val["CONCURRENT_SECONDS"] <= 1.55 * val["SERIAL_SECONDS"] + 0.05, val
 
 
 def test_jitter_fallback_on_the_lookahead_path():
