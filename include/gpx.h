@@ -299,6 +299,32 @@ int gpx_dev_chol_dataflow(double *L, int64_t ld, int64_t nblk, int64_t first_blo
 int gpx_adopt_factor(const double *x, const double *t_centered, int64_t n, int d, const double *theta, double *L_dev,
                      double *dinv_dev, double *diag_dev, double jitter, void *stream, gpx_handle **out);
 
+
+/* ---- e1-e4 behind the C-ABI: ONE host process driving several devices of one node (csrc/multi.hip) ----
+ * The reference has no distributed code (it factors on one host: skgpuppy/Covariance.py:179, and predicts with two dense products:
+ * skgpuppy/GaussianProcess.py:75-78); SURVEY.md 8b proposed gpx_set_devices(...) / a multi-GPU handle for the sharded path.  This is that
+ * handle -- the schedule of skgpuppy_amd/distributed.py (one process per GPU, torch.distributed) for callers without Python or a process
+ * launcher: sharded K-build, panel Cholesky with look-ahead and peer-to-peer panel messages, query-sharded estimate_many,
+ * right-hand-side-sharded propagate_GA.  devices[ndev]: HIP device ordinals, block-cyclic owners of the 1024-column panels; an ordinal may
+ * repeat (several logical ranks on one GPU: how the path is tested on a one-GPU box).  x [n, d], t_centered [n], theta [2 + d]: HOST
+ * arrays.  Every device ends with the complete factor (npad^2 doubles each).  Status as gpx_fit: > 0 = not positive definite also after
+ * the ONE collective retry on K + 1e-5 I (Covariance.py:180-185); a timed-out in-kernel hand-off is GPX_ERR_STATE, never jitter.
+ * Not thread-safe per handle; distinct handles may be used from distinct threads. */
+typedef struct gpx_multi gpx_multi;
+int  gpx_multi_fit(const double *x, const double *t_centered, int64_t n, int d, const double *theta, const int *devices, int ndev,
+                   gpx_multi **out);
+void gpx_multi_free(gpx_multi *m);
+int  gpx_multi_info(const gpx_multi *m, int *ndev, int64_t *npanels, double *jitter_used);
+/* beta = K^-1 t (GaussianProcess.py:114-119), from the first device's copy of the factor */
+int  gpx_multi_alpha(gpx_multi *m, double *beta_out);
+/* GaussianProcess.estimate_many (GaussianProcess.py:68-80) with the queries dealt to the devices in contiguous shards, no exchange;
+ * xs [m, d], mean_out / var_out [m] HOST arrays; mean WITHOUT meant */
+int  gpx_multi_predict(gpx_multi *m, const double *xs, int64_t nq, double *mean_out, double *var_out);
+/* UncertaintyPropagationApprox.propagate_GA (UncertaintyPropagation.py:397-479): the d + 1 right-hand sides [C, J_1..J_d] dealt to the
+ * devices (gpx_propagate_approx_rhs on each), the 4 + 2 d partial sums added on the host; outputs as gpx_propagate_approx (mean WITHOUT
+ * meant; sigma2 / rest optional) */
+int  gpx_multi_propagate_approx(gpx_multi *m, const double *u, const double *Sigma, double *mean, double *var, double *sigma2, double *rest);
+
 #ifdef __cplusplus
 }
 #endif

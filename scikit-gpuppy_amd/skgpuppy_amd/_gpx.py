@@ -92,6 +92,12 @@ SIGNATURES = {
                                         ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_dev_chol_dataflow": (_int, [_dp, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_adopt_factor": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.c_void_p, ctypes.POINTER(_hp)]),
+    "gpx_multi_fit": (_int, [_dp, _dp, _i64, _int, _dp, ctypes.POINTER(_int), _int, ctypes.POINTER(_hp)]),
+    "gpx_multi_free": (None, [_hp]),
+    "gpx_multi_info": (_int, [_hp, ctypes.POINTER(_int), ctypes.POINTER(_i64), ctypes.POINTER(_dbl)]),
+    "gpx_multi_alpha": (_int, [_hp, _dp]),
+    "gpx_multi_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
+    "gpx_multi_propagate_approx": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 4),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     try:

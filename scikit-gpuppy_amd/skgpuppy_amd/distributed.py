@@ -326,6 +326,7 @@ class GpxOps(object):
         self._ev_lookahead = {}                         # panel -> event: the main stream has applied every panel but the last one to it
         self._readers = {}                              # panel -> events behind every read of its message buffer
         self._local = {}                                # (own panel, part) -> event: that part's rows are solved (before pack and send)
+        self._ev_built = None                           # behind the last build_panel on the main stream (see factor_panel)
         # GPX_SHARD_TIMING=1 (bench): event pairs around the owner's chain (side stream; chol_panel_ms), from the point where the far
         # rows may start to the last row's solve (chol_panel_rows_ms = the whole panel step), around the side stream's wait for the head of the
         # panel before an owned one and around the main stream's wait for each panel's tail -- what the first multi-GPU run is judged
@@ -409,11 +410,13 @@ class GpxOps(object):
         if c0 >= n:      # panel entirely in the padding: identity
             self.L[c0:, c0:c0 + w].zero_()
             self.L[c0:c0 + w, c0:c0 + w].fill_diagonal_(1.0)
+            self._ev_built = self._event(self.main)
             return
         xi = ctypes.c_void_p(self.xw.data_ptr() + 8 * c0 * d)
         st = self.lib.gpx_dev_gram_scaled(xi, n - c0, xi, min(c0 + w, n) - c0, d, self.v, self.vt, 0, 1,
                                           self._Lptr(c0, c0), npad, npad - c0, w, self._stream_ptr(self.main))
         self._gpx.check(st, "gpx_dev_gram_scaled(panel %d)" % p)
+        self._ev_built = self._event(self.main)       # (recorded HERE, behind the builds alone -- not behind the updates main runs later)
 
     def _gemm(self, q0, q1, p, stream):
         """C[rows >= q0, columns q0..q1) -= P[rows >= q0] P[rows q0..q1)^T with P = the update operand of panel p"""
@@ -431,6 +434,12 @@ class GpxOps(object):
         hr = self.layout.head_rows(p)
         rowstreams = (self.head, self.far)
         self._shake()
+        # The panels were assembled on the MAIN stream.  Nothing else orders a rank's first owned panel behind its own Gram launch when
+        # that panel is not panel 0 (its chain waits for the previous panel's head, which travels on other streams): found while porting
+        # the schedule to csrc/multi.hip in round 6 -- hidden in practice (panel 0's factorisation takes longer than the builds).
+        if self._ev_built is not None:
+            for st in (self.side,) + rowstreams:
+                st.wait_event(self._ev_built)
         if prev is not None:
             # the chain needs the HEAD of `prev` (this panel's square rows of it) and the main stream's earlier updates of this
             # panel; the rows below the square need prev's TAIL as well

@@ -70,6 +70,12 @@ def test_no_device_is_an_error_not_a_fallback():
         skgpuppy_amd.GaussianProcess(x, np.zeros(5), cov, th)
     out = ctypes.c_double()
     assert _gpx.lib.gpx_bench_mfma_f64(10, ctypes.byref(out)) == _gpx.GPX_ERR_NO_DEVICE
+    # the multi-device handle (csrc/multi.hip) as well: no device, no fallback
+    h = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, 1)
+    t = np.zeros(5)
+    assert _gpx.lib.gpx_multi_fit(_gpx.ptr(_gpx.f64(x)), _gpx.ptr(t), 5, 2, _gpx.ptr(th), devs, 2, ctypes.byref(h)) == _gpx.GPX_ERR_NO_DEVICE
+    assert not h
 
 
 def test_product_never_imports_oracle():

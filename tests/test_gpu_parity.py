@@ -626,6 +626,74 @@ def test_sharded_fit_two_ranks_share_one_gpu(N, d, message, transport):
     assert ("panel message: head + tail" if message == "split" else "panel message: whole") + ", transport: " + transport in r.stdout
 
 
+_MULTI_WORKER = r"""
+import ctypes, sys
+import numpy as np
+sys.path.insert(0, %(pkg)r); sys.path.insert(0, %(root)r)
+import torch  # noqa: F401
+import skgpuppy_amd as sk
+from skgpuppy_amd import _gpx
+N, d, ndev, dup = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+rng = np.random.RandomState(20240 + N + d)
+x = rng.uniform(0, 10, (N, d)); t = np.sin(0.3 * x.sum(1)) + 0.1 * rng.randn(N); xs = rng.uniform(0, 10, (777, d))
+theta = np.log(np.array([2.0, 0.01] + [0.04] * d))
+if dup:                                              # a cluster of numerically identical rows well inside the matrix + vt = 0: non-positive pivot
+    x[N // 2:N // 2 + 150] = x[N // 2] + 1e-9 * rng.randn(150, d)
+    theta[1] = -np.inf
+tc = np.ascontiguousarray(t - t.mean())
+devs = (ctypes.c_int * ndev)(*([0] * ndev))
+h = ctypes.c_void_p()
+st = _gpx.lib.gpx_multi_fit(_gpx.ptr(_gpx.f64(x)), _gpx.ptr(tc), N, d, _gpx.ptr(_gpx.f64(theta)), devs, ndev, ctypes.byref(h))
+_gpx.check(st, "gpx_multi_fit")
+nd, npan, jit = ctypes.c_int(), ctypes.c_int64(), ctypes.c_double()
+_gpx.check(_gpx.lib.gpx_multi_info(h, ctypes.byref(nd), ctypes.byref(npan), ctypes.byref(jit)), "info")
+beta = np.empty(N); mean = np.empty(len(xs)); var = np.empty(len(xs))
+_gpx.check(_gpx.lib.gpx_multi_alpha(h, _gpx.ptr(beta)), "alpha")
+_gpx.check(_gpx.lib.gpx_multi_predict(h, _gpx.ptr(_gpx.f64(xs)), len(xs), _gpx.ptr(mean), _gpx.ptr(var)), "predict")
+u, S = np.full(d, 5.0), 0.01 * np.eye(d)
+pm, pv, s2, rest = (ctypes.c_double() for _ in range(4))
+_gpx.check(_gpx.lib.gpx_multi_propagate_approx(h, _gpx.ptr(u), _gpx.ptr(_gpx.f64(S)), ctypes.byref(pm), ctypes.byref(pv), ctypes.byref(s2), ctypes.byref(rest)), "propagate")
+# the single-GPU path on the same inputs
+with np.errstate(divide="ignore"):
+    gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
+    m1, v1 = gp.estimate_many(xs)
+    b1 = gp._get_beta()
+    a1 = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+scale = np.abs(b1).max()
+print("MULTI ndev %%d panels %%d jitter %%g single-gpu jitter %%g" %% (nd.value, npan.value, jit.value, gp._dev().jitter()))
+print("DBETA %%.3e" %% (np.abs(beta - b1).max() / scale))
+print("DMEAN %%.3e" %% np.abs(mean + gp.meant - m1).max())
+print("DVAR %%.3e" %% np.abs(var - v1).max())
+print("DPROP %%.3e %%.3e" %% (abs(pm.value + gp.meant - a1[0]), abs(pv.value - a1[1])))
+_gpx.lib.gpx_multi_free(h)
+"""
+
+
+@pytest.mark.parametrize("N,d,ndev,dup", [(2500, 3, 1, 0), (2500, 3, 3, 0), (8200, 6, 2, 0), (8200, 6, 3, 0), (5000, 4, 2, 1)])
+def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
+    """e1-e4 behind the C-ABI (gpx_multi_*, csrc/multi.hip): one host process, `ndev` logical ranks -- all on the one GPU of
+    the test box (device ordinals may repeat), so every rank has its own factor copy, streams and staging slots and panels travel by
+    hipMemcpyPeerAsync on the receivers' copy streams, ordered by events only.  Against the single-GPU path on the same inputs: alpha,
+    estimate_many (query-sharded), propagate_GA (right-hand-side-sharded).  8200 rows = 9 outer panels: every staging slot is reused;
+    dup = 1: a non-positive pivot in the middle of the matrix must be answered by ONE collective retry on K + 1e-5 I (Covariance.py:180-185)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = _MULTI_WORKER % {"root": ROOT, "pkg": os.path.join(ROOT, "scikit-gpuppy_amd")}
+    r = subprocess.run([sys.executable, "-c", code, str(N), str(d), str(ndev), str(dup)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    val = {l.split()[0]: [float(z) for z in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("D")}
+    head = [l for l in r.stdout.splitlines() if l.startswith("MULTI")][0].split()
+    print("multi-device ABI:", " ".join(head), val)
+    assert int(head[2]) == ndev and int(head[4]) == (N + 1023) // 1024
+    assert float(head[6]) == float(head[9]) == (1e-5 if dup else 0.0)          # both paths took (or did not take) the jitter retry
+    tol = 1e-6 if dup else 1e-9        # (vt = 0 with a near-singular cluster: cond(K + 1e-5 I) ~ 1e6, summation order shows)
+    assert val["DBETA"][0] < tol, val
+    assert val["DMEAN"][0] < tol and val["DVAR"][0] < tol, val
+    assert val["DPROP"][0] < tol and val["DPROP"][1] < 10 * tol, val
+
+
 @pytest.mark.parametrize("transport", ["host", "gloo-device", "gloo-device-chaos"])
 def test_sharded_fit_four_ranks_share_one_gpu_c3_size(transport):
     """The panel-sharded path with FOUR ranks on the one GPU at the C3 size (N = 16384: 16 outer panels, every rank owns four, the three
