@@ -330,6 +330,41 @@ def workload_point(lib, _gpx, name, warm, reps):
             "outputs_finite_and_var_positive": finite}
 
 
+def multi_abi_point(lib, _gpx, name="c3", ranks=(1, 2), reps=3):
+    """The single-process multi-device C-ABI (gpx_multi_*, csrc/multi.hip: the sharded schedule of SURVEY 8e without Python's launcher) on
+    the ONE GPU of this run, with 1 and 2 logical ranks on it (a device ordinal may repeat): a driver-witnessed functional figure at full
+    size -- ranks on one GPU share its CUs, so two cannot be faster here -- and the check that alpha equals gpx_fit's to the bit."""
+    wl = WORKLOADS[name]
+    N, d = wl["N"], wl["d"]
+    x, t, xs, theta = recipe(N, d, 4096)
+    x, tc, xs, th = np.ascontiguousarray(x), np.ascontiguousarray(t - t.mean()), np.ascontiguousarray(xs), np.ascontiguousarray(theta)
+    h = ctypes.c_void_p()
+    _gpx.check(lib.gpx_fit(_gpx.ptr(x), _gpx.ptr(tc), N, d, _gpx.ptr(th), None, ctypes.byref(h)), "gpx_fit")
+    ref = np.empty(N)
+    _gpx.check(lib.gpx_alpha(h, _gpx.ptr(ref)), "gpx_alpha")
+    lib.gpx_free(h)
+    out = {"workload": "%s: N=%d d=%d through gpx_multi_fit / gpx_multi_predict (4096 queries), host arrays in, logical ranks on cuda:0" % (name.upper(), N, d)}
+    for R in ranks:
+        devs = (ctypes.c_int * R)(*([0] * R))
+        best = None
+        for _ in range(1 + reps):
+            m = ctypes.c_void_p()
+            a = time.perf_counter()
+            _gpx.check(lib.gpx_multi_fit(_gpx.ptr(x), _gpx.ptr(tc), N, d, _gpx.ptr(th), devs, R, ctypes.byref(m)), "gpx_multi_fit")
+            b = time.perf_counter()
+            mean, var = np.empty(len(xs)), np.empty(len(xs))
+            _gpx.check(lib.gpx_multi_predict(m, _gpx.ptr(xs), len(xs), _gpx.ptr(mean), _gpx.ptr(var)), "gpx_multi_predict")
+            c = time.perf_counter()
+            beta = np.empty(N)
+            _gpx.check(lib.gpx_multi_alpha(m, _gpx.ptr(beta)), "gpx_multi_alpha")
+            lib.gpx_multi_free(m)
+            if best is None or b - a < best[0]:
+                best = (b - a, c - b)
+        out["ranks_%d" % R] = {"fit_ms": best[0] * 1e3, "predict_4096_ms": best[1] * 1e3, "max_abs_dalpha_vs_gpx_fit": float(np.abs(beta - ref).max()),
+                               "outputs_finite_and_var_positive": bool(np.isfinite(mean).all() and (var > 0).all())}
+    return out
+
+
 def propagate_parity(cb, d):
     """Config C3's second half against the oracle at the benchmark size: propagate_GA (Approx and Exact, u = 5 1_d, Sigma = 0.01 I)
     on a GPU fit of the oracle's inputs against oracle.approx_propagate / exact_propagate on the oracle's own K^-1 (serial C
@@ -524,6 +559,8 @@ def run_single(args):
             out["c2"] = workload_point(lib, _gpx, "c2", warm=3, reps=10)
             _gpx.lib.gpx_pool_trim()
             out["c4_one_gpu"] = workload_point(lib, _gpx, "c4", warm=1, reps=2)   # the one-GPU point of the N = 65536 scaling curve
+            _gpx.lib.gpx_pool_trim()
+            out["multi_abi"] = multi_abi_point(lib, _gpx)                        # e1-e4 behind the C-ABI, rehearsed with logical ranks on this GPU
             _gpx.lib.gpx_pool_trim()
     if not args.no_cpu:
         cb = cpu_baseline(N, d, M, budget_s=args.cpu_budget)

@@ -324,6 +324,9 @@ int  gpx_multi_predict(gpx_multi *m, const double *xs, int64_t nq, double *mean_
  * devices (gpx_propagate_approx_rhs on each), the 4 + 2 d partial sums added on the host; outputs as gpx_propagate_approx (mean WITHOUT
  * meant; sigma2 / rest optional) */
 int  gpx_multi_propagate_approx(gpx_multi *m, const double *u, const double *Sigma, double *mean, double *var, double *sigma2, double *rest);
+/* UncertaintyPropagationExact.propagate_GA (UncertaintyPropagation.py:246-379): row panels of equal triangle area, one per device
+ * (gpx_propagate_exact_rows: each device builds only its rows of K^-1), two partial sums added on the host; mean WITHOUT meant */
+int  gpx_multi_propagate_exact(gpx_multi *m, const double *u, const double *Sigma, double *mean, double *var);
 
 #ifdef __cplusplus
 }

@@ -71,6 +71,8 @@ extern "C" int gpx_set_device(int device)
     return 0;
 }
 
+int gpx_thread_device() { return g_device; }   // (multi.hip saves / restores the calling thread's choice around its per-device work)
+
 int gpx_require_device()
 {
     int n = gpx_device_count();

@@ -245,6 +245,7 @@ int gpx_require_device();
 // caching device allocator and stream cache (api.hip)
 int dalloc(double **p, int64_t elems);
 void dfree(void *p);
+int gpx_thread_device();   // the calling host thread's gpx_set_device choice (api.hip)
 hipStream_t stream_acquire(int high_priority);
 void stream_release(hipStream_t s, int high_priority);
 

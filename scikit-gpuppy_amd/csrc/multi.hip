@@ -237,11 +237,14 @@ void release_device(MDev &m)
     if (m.ev_built) { (void)hipEventDestroy(m.ev_built); m.ev_built = nullptr; }
     dfree(m.xw); dfree(m.L); dfree(m.Dinv); dfree(m.diag);
     for (int i = 0; i < NSLOTS; ++i) dfree(m.stage[i]);
-    if (m.info) (void)hipFree(m.info);
+    dfree(m.info);
     m.xw = m.L = m.Dinv = m.diag = nullptr;
     m.info = nullptr;
-    for (hipStream_t *s : {&m.main, &m.side, &m.copy})
-        if (*s) { (void)hipStreamDestroy(*s); *s = nullptr; }
+    for (int i = 0; i < NSLOTS; ++i) m.stage[i] = nullptr;
+    if (m.main) stream_release(m.main, 0);
+    if (m.side) stream_release(m.side, 1);
+    if (m.copy) stream_release(m.copy, 0);
+    m.main = m.side = m.copy = nullptr;
 }
 
 // one attempt of the sharded fit with the given jitter; *info_out = max of the devices' status words
@@ -309,13 +312,18 @@ int factor_all(gpx_multi *g, const double *x_host, int *info_out)
 }   // namespace
 
 // ---- C-ABI -------------------------------------------------------------------------------------------------------------------------------
+// the calling thread's device choice (the library's thread-local one and HIP's) is put back when a multi-device call returns
+struct DeviceGuard {
+    int gpx_dev = 0, hip_dev = 0;
+    DeviceGuard() : gpx_dev(gpx_thread_device()) { (void)hipGetDevice(&hip_dev); }
+    ~DeviceGuard() { (void)gpx_set_device(gpx_dev); (void)hipSetDevice(hip_dev); }
+};
+
 extern "C" void gpx_multi_free(gpx_multi *g)
 {
     if (!g) return;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    DeviceGuard guard;
     for (MDev &m : g->devs) release_device(m);
-    (void)hipSetDevice(cur);
     delete g;
 }
 
@@ -345,8 +353,7 @@ extern "C" int gpx_multi_fit(const double *x, const double *t_centered, int64_t 
     g->vt = std::exp(theta[1]);          // theta[1] = -inf: vt = 0
     g->devs.resize((size_t)ndev);
     int rc = 0;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
+    DeviceGuard guard;
     auto body = [&]() -> int {
         for (int r = 0; r < ndev; ++r) {
             MDev &m = g->devs[(size_t)r];
@@ -355,18 +362,23 @@ extern "C" int gpx_multi_fit(const double *x, const double *t_centered, int64_t 
             GPX_TRY(gpx_require_device());
             for (int q = 0; q < ndev; ++q)   // direct sends over xGMI ("already enabled" is fine; no peer path: the copy is staged by the runtime)
                 if (devices[q] != m.dev) { (void)hipDeviceEnablePeerAccess(devices[q], 0); (void)hipGetLastError(); }
-            int lo = 0, hi = 0;
-            GPX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            GPX_HIP(hipStreamCreateWithFlags(&m.main, hipStreamNonBlocking));
-            GPX_HIP(hipStreamCreateWithPriority(&m.side, hipStreamNonBlocking, hi));
-            GPX_HIP(hipStreamCreateWithFlags(&m.copy, hipStreamNonBlocking));
+            // streams from the library's per-device cache (creating and destroying three streams costs more than a small fit); the chain's
+            // stream in the high-priority class, like the single-GPU schedule's
+            m.main = stream_acquire(0);
+            m.side = stream_acquire(1);
+            m.copy = stream_acquire(0);
+            if (!m.main || !m.side || !m.copy) { gpx_set_error("gpx_multi_fit: no stream on device %d", m.dev); return GPX_ERR_HIP; }
             GPX_TRY(dalloc(&m.xw, n * d));
             GPX_TRY(dalloc(&m.L, g->npad * g->npad));
             GPX_TRY(dalloc(&m.Dinv, g->nblk * (int64_t)TILE * TILE));
             GPX_TRY(dalloc(&m.diag, g->npad));
             if (ndev > 1)
                 for (int i = 0; i < NSLOTS; ++i) GPX_TRY(dalloc(&m.stage[i], message_elems(g, 0)));
-            GPX_HIP(hipMalloc((void **)&m.info, 8 * sizeof(int)));
+            {
+                double *w = nullptr;
+                GPX_TRY(dalloc(&w, 8));
+                m.info = reinterpret_cast<int *>(w);
+            }
         }
         int info = 0;
         for (double jitter : {0.0, 1e-5}) {
@@ -387,8 +399,6 @@ extern "C" int gpx_multi_fit(const double *x, const double *t_centered, int64_t 
         return 0;
     };
     rc = body();
-    (void)gpx_set_device(cur);
-    (void)hipSetDevice(cur);
     if (rc) { gpx_multi_free(g); return rc; }
     *out = g;
     return 0;
@@ -406,6 +416,7 @@ extern "C" int gpx_multi_info(const gpx_multi *g, int *ndev, int64_t *npanels, d
 extern "C" int gpx_multi_alpha(gpx_multi *g, double *beta_out)
 {
     if (!g || !beta_out) { gpx_set_error("null argument"); return GPX_ERR_BAD_ARG; }
+    DeviceGuard guard;
     GPX_TRY(gpx_set_device(g->devs[0].dev));
     return gpx_alpha(g->devs[0].h, beta_out);
 }
@@ -475,5 +486,46 @@ extern "C" int gpx_multi_propagate_approx(gpx_multi *g, const double *u, const d
     if (var) *var = s2 + var2 + var3;
     if (sigma2) *sigma2 = s2;
     if (rest) *rest = var2 + var3;
+    return 0;
+}
+
+// e4, Exact: UncertaintyPropagationExact.propagate_GA (UncertaintyPropagation.py:246-379) -- the j <= i double sum over
+// (Kinv_ij - beta_i beta_j) L_ij cut into 128-aligned row panels of (almost) equal AREA of the triangle, one per device
+// (gpx_propagate_exact_rows: a device builds only ITS rows of K^-1), two partial sums added on the host; mean WITHOUT meant.
+extern "C" int gpx_multi_propagate_exact(gpx_multi *g, const double *u, const double *Sigma, double *mean, double *var)
+{
+    if (!g || !u || !Sigma) { gpx_set_error("gpx_multi_propagate_exact: bad arguments"); return GPX_ERR_BAD_ARG; }
+    const int R = (int)g->devs.size();
+    const int64_t nblk = (g->n + TILE - 1) / TILE;
+    std::vector<int64_t> cuts((size_t)R + 1);
+    for (int r = 0; r <= R; ++r) cuts[(size_t)r] = (int64_t)std::llround((double)nblk * std::sqrt((double)r / (double)R));
+    cuts[0] = 0;
+    cuts[(size_t)R] = nblk;
+    std::vector<std::vector<double>> part((size_t)R, std::vector<double>(3, 0.0));
+    std::vector<int> rcs((size_t)R, 0), used((size_t)R, 0);
+    std::vector<std::string> errs((size_t)R);
+    std::vector<std::thread> th;
+    for (int r = 0; r < R; ++r) {
+        const int64_t lo = std::min<int64_t>(g->n, cuts[(size_t)r] * TILE), hi = std::min<int64_t>(g->n, std::max(cuts[(size_t)r], cuts[(size_t)r + 1]) * TILE);
+        if (hi <= lo) continue;
+        used[(size_t)r] = 1;
+        th.emplace_back([&, r, lo, hi]() {
+            int rc = gpx_set_device(g->devs[(size_t)r].dev);
+            if (!rc) rc = gpx_propagate_exact_rows(g->devs[(size_t)r].h, u, Sigma, lo, hi, part[(size_t)r].data());
+            rcs[(size_t)r] = rc;
+            if (rc) errs[(size_t)r] = gpx_last_error();
+        });
+    }
+    for (std::thread &t : th) t.join();
+    double p0 = 0.0, p1 = 0.0, nc2 = 0.0;
+    for (int r = 0; r < R; ++r) {
+        if (rcs[(size_t)r]) { gpx_set_error("gpx_multi_propagate_exact (device %d): %s", g->devs[(size_t)r].dev, errs[(size_t)r].c_str()); return rcs[(size_t)r]; }
+        if (!used[(size_t)r]) continue;
+        p0 += part[(size_t)r][0];
+        p1 += part[(size_t)r][1];
+        nc2 = part[(size_t)r][2];
+    }
+    if (mean) *mean = p0;
+    if (var) *var = (g->v + g->vt) - nc2 * p1 - p0 * p0;      // UncertaintyPropagation.py:377
     return 0;
 }

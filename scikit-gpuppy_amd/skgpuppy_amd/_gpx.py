@@ -98,6 +98,7 @@ SIGNATURES = {
     "gpx_multi_alpha": (_int, [_hp, _dp]),
     "gpx_multi_predict": (_int, [_hp, _dp, _i64, _dp, _dp]),
     "gpx_multi_propagate_approx": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 4),
+    "gpx_multi_propagate_exact": (_int, [_hp, _dp, _dp] + [ctypes.POINTER(_dbl)] * 2),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     try:

@@ -653,18 +653,22 @@ _gpx.check(_gpx.lib.gpx_multi_predict(h, _gpx.ptr(_gpx.f64(xs)), len(xs), _gpx.p
 u, S = np.full(d, 5.0), 0.01 * np.eye(d)
 pm, pv, s2, rest = (ctypes.c_double() for _ in range(4))
 _gpx.check(_gpx.lib.gpx_multi_propagate_approx(h, _gpx.ptr(u), _gpx.ptr(_gpx.f64(S)), ctypes.byref(pm), ctypes.byref(pv), ctypes.byref(s2), ctypes.byref(rest)), "propagate")
+em, ev = ctypes.c_double(), ctypes.c_double()
+_gpx.check(_gpx.lib.gpx_multi_propagate_exact(h, _gpx.ptr(u), _gpx.ptr(_gpx.f64(S)), ctypes.byref(em), ctypes.byref(ev)), "propagate exact")
 # the single-GPU path on the same inputs
 with np.errstate(divide="ignore"):
     gp = sk.GaussianProcess(x, t, sk.GaussianCovariance(), theta.copy())
     m1, v1 = gp.estimate_many(xs)
     b1 = gp._get_beta()
     a1 = sk.UncertaintyPropagationApprox(gp).propagate_GA(u, S)
+    e1 = sk.UncertaintyPropagationExact(gp).propagate_GA(u, S)
 scale = np.abs(b1).max()
 print("MULTI ndev %%d panels %%d jitter %%g single-gpu jitter %%g" %% (nd.value, npan.value, jit.value, gp._dev().jitter()))
 print("DBETA %%.3e" %% (np.abs(beta - b1).max() / scale))
 print("DMEAN %%.3e" %% np.abs(mean + gp.meant - m1).max())
 print("DVAR %%.3e" %% np.abs(var - v1).max())
 print("DPROP %%.3e %%.3e" %% (abs(pm.value + gp.meant - a1[0]), abs(pv.value - a1[1])))
+print("DEXACT %%.3e %%.3e" %% (abs(em.value + gp.meant - e1[0]), abs(ev.value - e1[1])))
 _gpx.lib.gpx_multi_free(h)
 """
 
@@ -674,7 +678,7 @@ def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     """e1-e4 behind the C-ABI (gpx_multi_*, csrc/multi.hip): one host process, `ndev` logical ranks -- all on the one GPU of
     the test box (device ordinals may repeat), so every rank has its own factor copy, streams and staging slots and panels travel by
     hipMemcpyPeerAsync on the receivers' copy streams, ordered by events only.  Against the single-GPU path on the same inputs: alpha,
-    estimate_many (query-sharded), propagate_GA (right-hand-side-sharded).  8200 rows = 9 outer panels: every staging slot is reused;
+    estimate_many (query-sharded), propagate_GA Approx (right-hand-side-sharded) and Exact (row panels of equal triangle area).  8200 rows = 9 outer panels: every staging slot is reused;
     dup = 1: a non-positive pivot in the middle of the matrix must be answered by ONE collective retry on K + 1e-5 I (Covariance.py:180-185)."""
     import os
     import subprocess
@@ -692,6 +696,8 @@ def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     assert val["DBETA"][0] < tol, val
     assert val["DMEAN"][0] < tol and val["DVAR"][0] < tol, val
     assert val["DPROP"][0] < tol and val["DPROP"][1] < 10 * tol, val
+    # (Exact: row panels of K^-1 built per rank and summed in another order than the single-GPU pass over the whole matrix)
+    assert val["DEXACT"][0] < 10 * tol and val["DEXACT"][1] < 100 * tol, val
 
 
 @pytest.mark.parametrize("transport", ["host", "gloo-device", "gloo-device-chaos"])
