@@ -286,6 +286,11 @@ int gpx_dev_chol_panel_next(double *L, int64_t ld, int64_t nblk, int64_t B0, int
 int gpx_dev_chol_panel_split(double *L, int64_t ld, int64_t nblk, int64_t B0, int64_t B1, int64_t head_blocks, const double *prev,
                              int64_t ldp, int64_t kp, double *dinv, double *diag, int *info_dev, void *stream, void *stream_head,
                              void *stream_far);
+/* how many ranks share the trailing update that the CALLING THREAD's owner steps (gpx_dev_chol_panel / _next / _split) run beside; default 1.
+ * The step factors its diagonal square as ONE square launch of the dataflow kernel when the trailing update is short (fewer than 1000
+ * tiles) -- at R ranks that is decided on the tiles divided by R, an owner's chain running next to 1 / R of the update.  Set by the
+ * multi-GPU hosts (skgpuppy_amd/distributed.py, gpx_multi_fit); same arithmetic either way (bit-identical factor). */
+int gpx_dev_set_panel_share(int ranks);
 /* the factorisation (first_block = 0) or its trailing part (all updates from the block columns before first_block applied; first_block
  * a multiple of 8) as ONE persistent dataflow launch (csrc/dflow.hip): leaf, column solves, in-panel and trailing updates are tasks that
  * resident workgroups hand to each other through agent-scope counters instead of ~24 dependent launches per 1024-column panel.  This is what

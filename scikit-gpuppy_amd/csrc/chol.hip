@@ -395,6 +395,18 @@ __global__ void merge_info_kernel(const int *two, int *one)
 // of the dataflow kernel (dflow.hip; ~56 us per 128-column step instead of ~100-250 us of dependent launches that wait for places),
 // its column solves follow the launch's step counter.  (A panel solve by one product with the square's inverse was measured here too:
 // slower in the one-rank rehearsal, tools/native/rejected/r05_owner_step_square_launch_product_solve.patch.)
+// How many ranks share the trailing update this thread's owner steps run beside (gpx_dev_set_panel_share; 1 = all of it, the default).
+// At R ranks an owner's chain runs next to 1 / R of the update: "short trailing update -> square launch" is decided on the tiles divided
+// by R.  Measured where it can be on one GPU (profiles/r06_multi_device_abi_one_gpu.txt): square launches for EVERY panel cost one rank
+// nothing (C3 29.2 vs 29.3 ms, C4 1.371 vs 1.366 s) and take 6 % off two ranks that share the chip (39.2 vs 41.6 ms).
+static thread_local int g_panel_share = 1;
+extern "C" int gpx_dev_set_panel_share(int ranks)
+{
+    if (ranks < 1) { gpx_set_error("gpx_dev_set_panel_share: ranks must be >= 1"); return GPX_ERR_BAD_ARG; }
+    g_panel_share = ranks;
+    return 0;
+}
+
 int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0, int64_t B1, double *Dinv, double *diagL,
                             int *info_dev, hipStream_t s, Profiler *prof, const double *P, int64_t ldp, int64_t kp,
                             int64_t hb, hipStream_t sh, hipStream_t sf)
@@ -406,7 +418,7 @@ int chol_panel_factor_piped(double *L, int64_t ld, int64_t nblk_all, int64_t B0,
     const int64_t nrem = nblk_all - B1;
     static const int64_t sqk_from = [] { const char *e = getenv("GPX_SQK_FROM"); return e ? atol(e) : (int64_t)-2; }();
     const bool sqk = sqk_from != -1 && B1 - B0 == CHOL_NBP && B0 % CHOL_NBP == 0 && chol_dataflow_supported(CHOL_NBP) &&
-                     (sqk_from == 0 || B0 == 0 || nrem * (nrem + 1) / 2 + nrem * CHOL_NBP < 1000);
+                     (sqk_from == 0 || B0 == 0 || (nrem * (nrem + 1) / 2 + nrem * CHOL_NBP) / g_panel_share < 1000);
     std::vector<void *> scratch;
     int *two = nullptr, *state = nullptr, *tab_dev = nullptr;
     if (sqk) {

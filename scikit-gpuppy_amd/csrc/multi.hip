@@ -285,6 +285,7 @@ int factor_all(gpx_multi *g, const double *x_host, int *info_out)
             if (r != owner(g, p)) GPX_TRY(receive_panel(g, o, g->devs[(size_t)r], p));
         return 0;
     };
+    GPX_TRY(gpx_dev_set_panel_share(R));   // an owner's chain runs next to 1 / R of the trailing update (chol.hip, owner's step)
     GPX_TRY(post(0, -1));
     for (int64_t p = 0; p < P; ++p) {
         // host order: the (single, cheap to queue) trailing updates first, then the next panel's long chain of small launches -- on the
@@ -297,6 +298,7 @@ int factor_all(gpx_multi *g, const double *x_host, int *info_out)
         }
         if (p + 1 < P) GPX_TRY(post(p + 1, p));
     }
+    (void)gpx_dev_set_panel_share(1);
     int worst = 0;
     for (MDev &m : g->devs) {
         GPX_HIP(hipSetDevice(m.dev));

@@ -90,6 +90,7 @@ SIGNATURES = {
     "gpx_dev_chol_panel_next": (_int, [_dp, _i64, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_dev_chol_panel_split": (_int, [_dp, _i64, _i64, _i64, _i64, _i64, _dp, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "gpx_dev_set_panel_share": (_int, [_int]),
     "gpx_dev_chol_dataflow": (_int, [_dp, _i64, _i64, _i64, _dp, _dp, ctypes.c_void_p, ctypes.c_void_p]),
     "gpx_adopt_factor": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.c_void_p, ctypes.POINTER(_hp)]),
     "gpx_multi_fit": (_int, [_dp, _dp, _i64, _int, _dp, ctypes.POINTER(_int), _int, ctypes.POINTER(_hp)]),

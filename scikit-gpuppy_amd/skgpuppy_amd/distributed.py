@@ -298,6 +298,8 @@ class GpxOps(object):
         from . import _gpx
         self.torch, self._gpx, self.lib = torch, _gpx, _gpx.lib
         self.layout = layout
+        # an owner's chain runs next to 1 / world of the trailing update: the owner's step picks its square launches accordingly (gpx.h)
+        _gpx.check(self.lib.gpx_dev_set_panel_share(int(layout.world)), "gpx_dev_set_panel_share")
         self.rank = rank
         self.x = x_dev                                  # [n, d] float64 on `device`
         self.n, self.d = x_dev.shape
