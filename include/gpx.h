@@ -166,6 +166,14 @@ int gpx_exact_mean(gpx_handle *h, const double *u, const double *Sigma, double *
  * (propagate_mean(u, Sigma, C_ux), UncertaintyPropagation.py:269-290) -- beta . (C corr), no K^-1 is built or read (Kinv may be NULL). */
 int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d, const double *w,
                                const double *C_ux, const double *u, const double *Sigma, double cuu, double *mean, double *var);
+/* the explicit form for MANY calls on one model (an SPGP GP's dense Kinv attribute and beta = Kinv t; any caller-held inverse): Kinv [n, n]
+ * and beta [n] are uploaded, padded and symmetrised ONCE (gpx_propagate_exact_matrix with h == NULL does that on every call: N^2 doubles
+ * over PCIe each time); then per call only x, C_ux, u, Sigma travel.  Same arithmetic as gpx_propagate_exact_matrix. */
+typedef struct gpx_kinv_model gpx_kinv_model;
+int  gpx_kinv_model_create(const double *Kinv, const double *beta, int64_t n, gpx_kinv_model **out);
+void gpx_kinv_model_free(gpx_kinv_model *m);
+int  gpx_propagate_exact_model(gpx_kinv_model *m, const double *x, int d, const double *w, const double *C_ux, const double *u,
+                               const double *Sigma, double cuu, double *mean, double *var);
 
 /* ---- "next" row f1: hyper-parameter likelihood at the handle's theta
  * (Covariance._negativeloglikelihood / _d_nll_d_theta, skgpuppy/Covariance.py:197-216, :266-282, :605-657) ----

@@ -1435,23 +1435,44 @@ __global__ __launch_bounds__(256) void mean_lower_pad_kernel(double *A, long ld,
     for (long j = n + threadIdx.x; j < np; j += 256) A[i * ld + j] = 0.0;
 }
 
-extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d,
-                                          const double *w, const double *C_ux, const double *u, const double *Sigma, double cuu,
-                                          double *mean, double *var)
+// An explicit K^-1 / beta kept on the device across calls (gpx_kinv_model_*): uploaded, padded to the tile grid and symmetrised ONCE.
+// Uncertainty propagation is typically called many times on one model; without this every call of the h == NULL form moved N^2 doubles
+// over PCIe again.
+struct gpx_kinv_model {
+    int device = 0;
+    int64_t n = 0, np = 0;
+    double *Kp = nullptr;     // [np, np]: lower triangle = mean of both triangles of the supplied matrix, zero padding
+    double *bpad = nullptr;   // [np]: beta, zero padded
+};
+
+// device copies of an explicit K^-1 (optional) and beta on stream s; the caller synchronises and frees
+static int upload_explicit(const double *Kinv, const double *beta, int64_t n, int64_t np, bool want_kinv, hipStream_t s, double **Kp, double **bpad)
 {
-    GPX_TRY(gpx_require_device());
-    if (h) GPX_HIP(hipSetDevice(h->device));
-    if (!x || !w || !C_ux || !u || !Sigma || n < 1 || d < 1 || d > GPX_MAX_D || (!h && (!beta || (var && !Kinv))) || (h && h->n != n)) {
-        gpx_set_error("gpx_propagate_exact_matrix: bad arguments (n=%ld d=%d%s)", (long)n, d, (h && h->n != n) ? ": the handle holds another n" : "");
-        return GPX_ERR_BAD_ARG;
+    *Kp = nullptr;
+    *bpad = nullptr;
+    GPX_TRY(dalloc(bpad, np));
+    GPX_HIP(hipMemsetAsync(*bpad, 0, sizeof(double) * np, s));
+    GPX_HIP(hipMemcpyAsync(*bpad, beta, sizeof(double) * n, hipMemcpyDefault, s));
+    if (want_kinv) {
+        // K^-1 goes row by row straight into ONE buffer padded to the tile grid (the padding never enters: F = 0 there).  The pair kernel
+        // visits j <= i only (weight 2) where the reference sums both triangles: the lower triangle of a supplied K^-1 becomes the mean of
+        // both (a Woodbury-built inverse is symmetric to rounding only).
+        GPX_TRY(dalloc(Kp, np * np));
+        GPX_HIP(hipMemcpy2DAsync(*Kp, sizeof(double) * np, Kinv, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDefault, s));
+        hipLaunchKernelGGL(mean_lower_pad_kernel, dim3((unsigned)np), dim3(256), 0, s, *Kp, (long)np, (long)n, (long)np);
+        GPX_HIP(hipGetLastError());
     }
+    return 0;
+}
+
+// Girard's exact moments from device-resident K^-1 (kbase [np, np], null: mean only) and beta (bdev [np]); everything else from the caller
+static int exact_matrix_core(hipStream_t s, Profiler *prof, const double *kbase, const double *bdev, const double *x, int64_t n, int d, const double *w,
+                             const double *C_ux, const double *u, const double *Sigma, double cuu, double *mean, double *var)
+{
     for (int k = 0; k < d; ++k)
         if (!(w[k] > 0.0) || !isfinite(w[k])) { gpx_set_error("gpx_propagate_exact_matrix: w[%d]=%g", k, w[k]); return GPX_ERR_BAD_ARG; }
     const int64_t np = round_up(n, TILE);
-    hipStream_t s = h ? h->stream : nullptr;
-    const double *kbase = nullptr, *bdev = nullptr;
-    const bool want_var = var != nullptr;   // the mean is beta . l alone: no K^-1 (46 ms to build at C3), no N^2 pass
-    if (h) { if (want_var) { GPX_TRY(ensure_kinv(h)); kbase = h->Kinv; } bdev = h->alpha; }
+    const bool want_var = var != nullptr && kbase != nullptr;
     // constants (UncertaintyPropagation.py:247-257, :292-303) exactly as exact_common builds them
     std::vector<double> A((size_t)d * d), Ai((size_t)d * d), Ls((size_t)d * d), dd(d);
     double nc1 = 1.0, nc2 = 1.0;
@@ -1472,11 +1493,11 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
             const double lji = (i == j ? 2.0 * w[i] : 0.0) - Ai[(size_t)j * d + i];
             Ls[(size_t)i * d + j] = 0.5 * (lij + lji);
         }
-    double *buf = nullptr, *Kp = nullptr;
+    double *buf = nullptr;
     const int64_t need = (2 * (int64_t)d + 6) * np + n * (int64_t)d + (int64_t)d * d + 2 * d + 8;
     GPX_TRY(dalloc(&buf, need));
     double *aT = buf, *bT = aT + (int64_t)d * np, *e = bT + (int64_t)d * np, *F = e + np, *lm = F + np, *partial = lm + np;
-    double *Cd = partial + np, *bpad = Cd + np, *xd = bpad + np, *Lsd = xd + n * (int64_t)d, *ddd = Lsd + (int64_t)d * d, *ud = ddd + d, *outd = ud + d;
+    double *Cd = partial + np, *xd = Cd + np, *Lsd = xd + n * (int64_t)d, *ddd = Lsd + (int64_t)d * d, *ud = ddd + d, *outd = ud + d;
     double o[2] = {0, 0};
     int rc = 0;
     hipError_t er = hipSuccess;
@@ -1486,36 +1507,81 @@ extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, con
         if ((er = hipMemcpyAsync(ud, u, sizeof(double) * d, hipMemcpyDefault, s)) != hipSuccess) break;
         if ((er = hipMemcpyAsync(xd, x, sizeof(double) * n * d, hipMemcpyDefault, s)) != hipSuccess) break;
         if ((er = hipMemcpyAsync(Cd, C_ux, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
-        if (!h) {
-            // explicit K^-1 / beta: zero-padded beta; K^-1 goes row by row straight into ONE buffer padded to the tile grid (the
-            // padding never enters: F = 0 there).  The pair kernel visits j <= i only (weight 2) where the reference sums both
-            // triangles: the lower triangle of a supplied K^-1 becomes the mean of both (a Woodbury-built inverse is symmetric to
-            // rounding only).  Mean only: no K^-1 at all.
-            if (want_var) {
-                if ((rc = dalloc(&Kp, np * np))) break;
-                if ((er = hipMemcpy2DAsync(Kp, sizeof(double) * np, Kinv, sizeof(double) * n, sizeof(double) * n, n, hipMemcpyDefault, s)) != hipSuccess) break;
-                hipLaunchKernelGGL(mean_lower_pad_kernel, dim3((unsigned)np), dim3(256), 0, s, Kp, (long)np, (long)n, (long)np);
-                kbase = Kp;
-            }
-            if ((er = hipMemsetAsync(bpad, 0, sizeof(double) * np, s)) != hipSuccess) break;
-            if ((er = hipMemcpyAsync(bpad, beta, sizeof(double) * n, hipMemcpyDefault, s)) != hipSuccess) break;
-            bdev = bpad;
-        }
         if ((rc = launch_exact_build_generic(xd, n, np, d, ud, Lsd, ddd, Cd, nc1, aT, bT, e, F, lm, s))) break;
         std::vector<std::pair<const double *, const double *>> pr;
         pr.push_back({bdev, lm});
         if ((rc = launch_dot_pairs(pr, np, outd, s))) break;
-        if (want_var && (rc = launch_exact_sum(kbase, np, np, d, bdev, aT, bT, e, F, partial, outd + 1, s, h ? &h->prof : nullptr))) break;
+        if (want_var && (rc = launch_exact_sum(kbase, np, np, d, bdev, aT, bT, e, F, partial, outd + 1, s, prof))) break;
         if ((er = hipMemcpyAsync(o, outd, sizeof(double) * (want_var ? 2 : 1), hipMemcpyDeviceToHost, s)) != hipSuccess) break;
     } while (0);
     const hipError_t es = hipStreamSynchronize(s);
     dfree(buf);
-    if (Kp) dfree(Kp);
     if (rc) return rc;
     if (er != hipSuccess || es != hipSuccess) { gpx_set_error("gpx_propagate_exact_matrix: %s", hipGetErrorString(er != hipSuccess ? er : es)); return GPX_ERR_HIP; }
     if (mean) *mean = o[0];
     if (var) *var = cuu - nc2 * o[1] - o[0] * o[0];   // UncertaintyPropagation.py:377
     return 0;
+}
+
+extern "C" int gpx_propagate_exact_matrix(gpx_handle *h, const double *Kinv, const double *beta, const double *x, int64_t n, int d,
+                                          const double *w, const double *C_ux, const double *u, const double *Sigma, double cuu,
+                                          double *mean, double *var)
+{
+    GPX_TRY(gpx_require_device());
+    if (h) GPX_HIP(hipSetDevice(h->device));
+    if (!x || !w || !C_ux || !u || !Sigma || n < 1 || d < 1 || d > GPX_MAX_D || (!h && (!beta || (var && !Kinv))) || (h && h->n != n)) {
+        gpx_set_error("gpx_propagate_exact_matrix: bad arguments (n=%ld d=%d%s)", (long)n, d, (h && h->n != n) ? ": the handle holds another n" : "");
+        return GPX_ERR_BAD_ARG;
+    }
+    const bool want_var = var != nullptr;   // the mean is beta . l alone: no K^-1 (46 ms to build at C3), no N^2 pass
+    if (h) {
+        if (want_var) GPX_TRY(ensure_kinv(h));
+        return exact_matrix_core(h->stream, &h->prof, want_var ? h->Kinv : nullptr, h->alpha, x, n, d, w, C_ux, u, Sigma, cuu, mean, var);
+    }
+    // explicit K^-1 / beta, one call: upload, use, free (many calls on one model: gpx_kinv_model_create + gpx_propagate_exact_model)
+    const int64_t np = round_up(n, TILE);
+    double *Kp = nullptr, *bpad = nullptr;
+    int rc = upload_explicit(Kinv, beta, n, np, want_var, nullptr, &Kp, &bpad);
+    if (!rc) rc = exact_matrix_core(nullptr, nullptr, Kp, bpad, x, n, d, w, C_ux, u, Sigma, cuu, mean, var);
+    (void)hipStreamSynchronize(nullptr);
+    dfree(Kp);
+    dfree(bpad);
+    return rc;
+}
+
+extern "C" int gpx_kinv_model_create(const double *Kinv, const double *beta, int64_t n, gpx_kinv_model **out)
+{
+    if (out) *out = nullptr;
+    GPX_TRY(gpx_require_device());
+    if (!Kinv || !beta || !out || n < 1) { gpx_set_error("gpx_kinv_model_create: bad arguments"); return GPX_ERR_BAD_ARG; }
+    gpx_kinv_model *m = new gpx_kinv_model();
+    GPX_HIP(hipGetDevice(&m->device));
+    m->n = n;
+    m->np = round_up(n, TILE);
+    int rc = upload_explicit(Kinv, beta, n, m->np, true, nullptr, &m->Kp, &m->bpad);
+    const hipError_t e = hipStreamSynchronize(nullptr);
+    if (!rc && e != hipSuccess) { gpx_set_error("gpx_kinv_model_create: %s", hipGetErrorString(e)); rc = GPX_ERR_HIP; }
+    if (rc) { dfree(m->Kp); dfree(m->bpad); delete m; return rc; }
+    *out = m;
+    return 0;
+}
+
+extern "C" void gpx_kinv_model_free(gpx_kinv_model *m)
+{
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    dfree(m->Kp);
+    dfree(m->bpad);
+    delete m;
+}
+
+extern "C" int gpx_propagate_exact_model(gpx_kinv_model *m, const double *x, int d, const double *w, const double *C_ux, const double *u,
+                                         const double *Sigma, double cuu, double *mean, double *var)
+{
+    if (!m || !x || !w || !C_ux || !u || !Sigma || d < 1 || d > GPX_MAX_D) { gpx_set_error("gpx_propagate_exact_model: bad arguments"); return GPX_ERR_BAD_ARG; }
+    GPX_HIP(hipSetDevice(m->device));
+    return exact_matrix_core(nullptr, nullptr, m->Kp, m->bpad, x, m->n, d, w, C_ux, u, Sigma, cuu, mean, var);
 }
 
 // ---- a4 with a caller-supplied matrix: Covariance.inv_cov_matrix(x, theta, cov_matrix=K) = inv(K)

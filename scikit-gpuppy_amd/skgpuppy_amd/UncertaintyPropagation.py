@@ -219,6 +219,27 @@ class UncertaintyPropagationApprox(UncertaintyPropagationGA):
         return out[h]
 
 
+class _ExplicitInverse(object):
+    """Owner of one gpx_kinv_model: an explicit K^-1 / beta resident in HBM (gpx.h)."""
+
+    def __init__(self, Kinv, beta, n):
+        self._h = ctypes.c_void_p()
+        _gpx.check(_gpx.lib.gpx_kinv_model_create(_gpx.ptr(Kinv), _gpx.ptr(beta), n, ctypes.byref(self._h)), "gpx_kinv_model_create")
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("explicit-inverse model already released")
+        return self._h
+
+    def close(self, _free=_gpx.lib.gpx_kinv_model_free, _null=ctypes.c_void_p):
+        if getattr(self, "_h", None):
+            _free(self._h)
+            self._h = _null()
+
+    __del__ = close
+
+
 class UncertaintyPropagationExact(UncertaintyPropagationGA):
     """Girard's exact Gaussian-approximation moments (UncertaintyPropagation.py:246-379 /
     UncertaintyPropagation2.pyx:57-184)."""
@@ -273,13 +294,34 @@ class UncertaintyPropagationExact(UncertaintyPropagationGA):
             st = _gpx.lib.gpx_propagate_exact_matrix(gp._dev().handle, None, None, _gpx.ptr(x), gp.n, gp.d, _gpx.ptr(w), _gpx.ptr(C),
                                                      _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), pvar)
         else:
-            # (SPGP: the model's dense K^-1 -- what the reference's class reads through _inv_cov_matrix -- and beta = Kinv t)
-            Kinv = _gpx.f64(gp._inv_cov_matrix()) if want_var else None
-            beta = _gpx.f64(gp._get_beta())
-            st = _gpx.lib.gpx_propagate_exact_matrix(None, _gpx.ptr(Kinv) if want_var else None, _gpx.ptr(beta), _gpx.ptr(x), gp.n, gp.d,
-                                                     _gpx.ptr(w), _gpx.ptr(C), _gpx.ptr(uu), _gpx.ptr(S), cuu, ctypes.byref(mean), pvar)
+            # (SPGP: the model's dense K^-1 -- what the reference's class reads through _inv_cov_matrix -- and beta = Kinv t: kept on the
+            # device across calls, uploaded once per Kinv array: gpx_kinv_model_*)
+            st = _gpx.lib.gpx_propagate_exact_model(self._explicit_model(gp), _gpx.ptr(x), gp.d, _gpx.ptr(w), _gpx.ptr(C), _gpx.ptr(uu),
+                                                    _gpx.ptr(S), cuu, ctypes.byref(mean), pvar)
         _gpx.check(st, "gpx_propagate_exact_matrix")
         return mean.value, var.value
+
+    def _explicit_model(self, gp):
+        """device copy of the GP's dense Kinv attribute and beta (padded, symmetrised), rebuilt only when the GP holds another Kinv array"""
+        Kinv = gp._inv_cov_matrix()
+        key = (id(Kinv), Kinv.__array_interface__["data"][0], Kinv.shape)
+        cached = getattr(self, "_kinv_model", None)
+        if cached is not None and cached[0] == key:
+            return cached[1].handle
+        self._release_explicit_model()
+        self._kinv_model = (key, _ExplicitInverse(_gpx.f64(Kinv), _gpx.f64(gp._get_beta()), gp.n), Kinv)   # (Kinv kept alive: its id is the key)
+        return self._kinv_model[1].handle
+
+    def _release_explicit_model(self):
+        cached = getattr(self, "_kinv_model", None)
+        if cached is not None:
+            cached[1].close()
+            self._kinv_model = None
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_kinv_model", None)          # device handles never enter a pickle
+        return state
 
     def propagate_mean(self, u, Sigma_x, C_ux=None):
         # (UncertaintyPropagation.py:269-290).  A caller-supplied C_ux is USED, as in the reference's class (sum_i beta_i C_ux_i corr_i):

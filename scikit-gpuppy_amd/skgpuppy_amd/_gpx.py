@@ -66,6 +66,9 @@ SIGNATURES = {
     "gpx_propagate_exact_rows": (_int, [_hp, _dp, _dp, _i64, _i64, _dp]),
     "gpx_exact_mean": (_int, [_hp, _dp, _dp, ctypes.POINTER(_dbl)]),
     "gpx_propagate_exact_matrix": (_int, [_hp, _dp, _dp, _dp, _i64, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
+    "gpx_kinv_model_create": (_int, [_dp, _dp, _i64, ctypes.POINTER(_hp)]),
+    "gpx_kinv_model_free": (None, [_hp]),
+    "gpx_propagate_exact_model": (_int, [_hp, _dp, _int, _dp, _dp, _dp, _dp, _dbl, ctypes.POINTER(_dbl), ctypes.POINTER(_dbl)]),
     "gpx_nll": (_int, [_hp, ctypes.POINTER(_dbl)]),
     "gpx_nll_grad": (_int, [_hp, _dp]),
     "gpx_spgp_fit": (_int, [_dp, _dp, _i64, _int, _dp, _dp, _i64, ctypes.POINTER(_hp)]),

@@ -1005,6 +1005,22 @@ def test_spgp_golden(name):
         me, ve = upe.propagate_GA(g["exact_u"], g["exact_Sigma"])
         np.testing.assert_allclose([me, ve], np.ravel(g["exact"]), rtol=0, atol=1e-6 * v)
         np.testing.assert_allclose(upe.propagate_mean(g["exact_u"], g["exact_Sigma"]), float(g["exact_mean_only"]), rtol=0, atol=1e-6)
+        # the dense K^-1 / beta stay on the device across calls (gpx_kinv_model_*: uploaded once per Kinv array), and the resident form
+        # gives the one-shot form's numbers to the bit (gpx_propagate_exact_matrix with h == NULL: upload, use, free)
+        model = upe._kinv_model[1].handle.value
+        me2, ve2 = upe.propagate_GA(g["exact_u"], g["exact_Sigma"])
+        assert upe._kinv_model[1].handle.value == model and (me2, ve2) == (me, ve)
+        import ctypes
+        from skgpuppy_amd import _gpx
+        xg, n, d = _gpx.f64(gp.x), gp.n, gp.d
+        C = _gpx.f64(np.array([gp._covariance(g["exact_u"], gp.x[i]) for i in range(n)]))
+        w, uu, S = _gpx.f64(np.diag(gp._get_W_inv())), _gpx.f64(g["exact_u"]), _gpx.f64(g["exact_Sigma"])
+        Kinv, beta = _gpx.f64(gp._inv_cov_matrix()), _gpx.f64(gp._get_beta())
+        m1, v1 = ctypes.c_double(), ctypes.c_double()
+        _gpx.check(_gpx.lib.gpx_propagate_exact_matrix(None, _gpx.ptr(Kinv), _gpx.ptr(beta), _gpx.ptr(xg), n, d, _gpx.ptr(w), _gpx.ptr(C), _gpx.ptr(uu),
+                                                       _gpx.ptr(S), float(gp._covariance(g["exact_u"], g["exact_u"])), ctypes.byref(m1), ctypes.byref(v1)),
+                   "gpx_propagate_exact_matrix")
+        assert m1.value + gp._get_mean_t() == me and v1.value == ve
 
 
 def test_spgp_vs_oracle_ragged_and_large_m():
