@@ -673,7 +673,7 @@ _gpx.lib.gpx_multi_free(h)
 """
 
 
-@pytest.mark.parametrize("N,d,ndev,dup", [(2500, 3, 1, 0), (2500, 3, 3, 0), (8200, 6, 2, 0), (8200, 6, 3, 0), (5000, 4, 2, 1)])
+@pytest.mark.parametrize("N,d,ndev,dup", [(2500, 3, 1, 0), (2500, 3, 3, 0), (8200, 6, 2, 0), (8200, 6, 3, 0), (5000, 4, 2, 1), (900, 2, 3, 0)])   # (900 rows: ONE panel, two ranks own nothing)
 def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     """e1-e4 behind the C-ABI (gpx_multi_*, csrc/multi.hip): one host process, `ndev` logical ranks -- all on the one GPU of
     the test box (device ordinals may repeat), so every rank has its own factor copy, streams and staging slots and panels travel by
