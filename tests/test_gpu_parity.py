@@ -700,6 +700,32 @@ def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     assert val["DEXACT"][0] < 10 * tol and val["DEXACT"][1] < 100 * tol, val
 
 
+def test_multi_device_abi_rejects_bad_arguments():
+    """gpx_multi_fit: a device ordinal that does not exist, a non-finite hyper-parameter, no devices -> GPX_ERR_BAD_ARG and no handle;
+    gpx_kinv_model_create / gpx_propagate_exact_model: null pointers -> GPX_ERR_BAD_ARG."""
+    import ctypes
+    from skgpuppy_amd import _gpx
+    rng = np.random.RandomState(3)
+    x, t, th = _gpx.f64(rng.rand(300, 2)), _gpx.f64(rng.rand(300)), _gpx.f64(np.log([2.0, 0.01, 0.04, 0.04]))
+    h = ctypes.c_void_p()
+    bad = (ctypes.c_int * 2)(0, 99)
+    assert _gpx.lib.gpx_multi_fit(_gpx.ptr(x), _gpx.ptr(t), 300, 2, _gpx.ptr(th), bad, 2, ctypes.byref(h)) == _gpx.GPX_ERR_BAD_ARG and not h
+    assert b"99" in _gpx.lib.gpx_last_error()
+    ok = (ctypes.c_int * 1)(0)
+    assert _gpx.lib.gpx_multi_fit(_gpx.ptr(x), _gpx.ptr(t), 300, 2, _gpx.ptr(th), ok, 0, ctypes.byref(h)) == _gpx.GPX_ERR_BAD_ARG and not h
+    thn = th.copy()
+    thn[2] = np.nan
+    assert _gpx.lib.gpx_multi_fit(_gpx.ptr(x), _gpx.ptr(t), 300, 2, _gpx.ptr(thn), ok, 1, ctypes.byref(h)) == _gpx.GPX_ERR_BAD_ARG and not h
+    assert _gpx.lib.gpx_multi_predict(None, _gpx.ptr(x), 300, _gpx.ptr(t), _gpx.ptr(t)) == _gpx.GPX_ERR_BAD_ARG
+    m = ctypes.c_void_p()
+    assert _gpx.lib.gpx_kinv_model_create(None, _gpx.ptr(t), 300, ctypes.byref(m)) == _gpx.GPX_ERR_BAD_ARG and not m
+    mean = ctypes.c_double()
+    assert _gpx.lib.gpx_propagate_exact_model(None, _gpx.ptr(x), 2, _gpx.ptr(th), _gpx.ptr(t), _gpx.ptr(th), _gpx.ptr(th), 1.0, ctypes.byref(mean), None) == _gpx.GPX_ERR_BAD_ARG
+    # and a good call still works afterwards (the caller's device choice was put back)
+    assert _gpx.lib.gpx_multi_fit(_gpx.ptr(x), _gpx.ptr(_gpx.f64(t - t.mean())), 300, 2, _gpx.ptr(th), ok, 1, ctypes.byref(h)) == 0 and h
+    _gpx.lib.gpx_multi_free(h)
+
+
 @pytest.mark.parametrize("transport", ["host", "gloo-device", "gloo-device-chaos"])
 def test_sharded_fit_four_ranks_share_one_gpu_c3_size(transport):
     """The panel-sharded path with FOUR ranks on the one GPU at the C3 size (N = 16384: 16 outer panels, every rank owns four, the three
