@@ -78,6 +78,29 @@ def test_no_device_is_an_error_not_a_fallback():
     assert not h
 
 
+def _build_c_caller(tmp_path):
+    import shutil
+    import subprocess
+    libdir = os.path.join(ROOT, "scikit-gpuppy_amd", "skgpuppy_amd")
+    exe = str(tmp_path / "multi_abi_from_c")
+    cmd = [shutil.which("gcc") or "gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "native", "multi_abi_from_c.c"),
+           "-L", libdir, "-lgpx", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return exe
+
+
+def test_plain_c_caller_compiles_against_the_header_and_links(tmp_path):
+    """include/gpx.h is a C header (no C++ in it) and libgpx.so resolves everything a plain C program needs for the sharded path
+    (gpx_multi_*): tests/native/multi_abi_from_c.c builds with gcc -Wall -Werror; without a device it reports GPX_ERR_NO_DEVICE (exit 3)."""
+    import subprocess
+    exe = _build_c_caller(tmp_path)
+    if not have_gpu():
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 3, (r.returncode, r.stdout[-500:], r.stderr[-500:])
+        assert "no device" in r.stdout
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "scikit-gpuppy_amd")
     for dirpath, _dirs, files in os.walk(pkg):

@@ -700,6 +700,17 @@ def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     assert val["DEXACT"][0] < 10 * tol and val["DEXACT"][1] < 100 * tol, val
 
 
+def test_multi_device_abi_from_plain_c(tmp_path):
+    """the sharded path reached from a plain C program (tests/native/multi_abi_from_c.c: gcc against include/gpx.h, three logical ranks
+    on the GPU): fit, estimate_many and propagate_GA agree with gpx_fit / gpx_predict / gpx_propagate_approx called from the same program."""
+    import subprocess
+    from test_abi import _build_c_caller
+    exe = _build_c_caller(tmp_path)
+    r = subprocess.run([exe, "3000", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1000:], r.stderr[-1000:])
+    assert "3 ranks" in r.stdout and "3 panels" in r.stdout
+
+
 def test_multi_device_abi_rejects_bad_arguments():
     """gpx_multi_fit: a device ordinal that does not exist, a non-finite hyper-parameter, no devices -> GPX_ERR_BAD_ARG and no handle;
     gpx_kinv_model_create / gpx_propagate_exact_model: null pointers -> GPX_ERR_BAD_ARG."""
