@@ -673,8 +673,10 @@ _gpx.lib.gpx_multi_free(h)
 """
 
 
-@pytest.mark.parametrize("N,d,ndev,dup", [(2500, 3, 1, 0), (2500, 3, 3, 0), (8200, 6, 2, 0), (8200, 6, 3, 0), (5000, 4, 2, 1), (900, 2, 3, 0)])   # (900 rows: ONE panel, two ranks own nothing)
-def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
+@pytest.mark.parametrize("N,d,ndev,dup,message", [(2500, 3, 1, 0, ""), (2500, 3, 3, 0, ""), (8200, 6, 2, 0, ""), (8200, 6, 3, 0, ""), (5000, 4, 2, 1, ""),
+                                                  (900, 2, 3, 0, ""),            # (900 rows: ONE panel, two ranks own nothing)
+                                                  (8200, 6, 3, 0, "split"), (8200, 6, 2, 0, "split"), (8200, 6, 1, 0, "split")])   # head + tail messages (the default only for ranks on different devices)
+def test_multi_device_abi_on_one_gpu(N, d, ndev, dup, message):
     """e1-e4 behind the C-ABI (gpx_multi_*, csrc/multi.hip): one host process, `ndev` logical ranks -- all on the one GPU of
     the test box (device ordinals may repeat), so every rank has its own factor copy, streams and staging slots and panels travel by
     hipMemcpyPeerAsync on the receivers' copy streams, ordered by events only.  Against the single-GPU path on the same inputs: alpha,
@@ -685,7 +687,10 @@ def test_multi_device_abi_on_one_gpu(N, d, ndev, dup):
     import sys
     from conftest import ROOT
     code = _MULTI_WORKER % {"root": ROOT, "pkg": os.path.join(ROOT, "scikit-gpuppy_amd")}
-    r = subprocess.run([sys.executable, "-c", code, str(N), str(d), str(ndev), str(dup)], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if message:
+        env["GPX_PANEL_MESSAGE"] = message     # default: head (the next panel's square rows) + tail for ranks on different devices, else one message
+    r = subprocess.run([sys.executable, "-c", code, str(N), str(d), str(ndev), str(dup)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     val = {l.split()[0]: [float(z) for z in l.split()[1:]] for l in r.stdout.splitlines() if l.startswith("D")}
     head = [l for l in r.stdout.splitlines() if l.startswith("MULTI")][0].split()
